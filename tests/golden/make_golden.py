@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference implementation.
+
+Run in the build container only (the reference is mounted read-only at /root/reference and never
+travels to the GPU box):
+
+    python tests/golden/make_golden.py [--reference /root/reference] [--only G4,G5]
+
+Nothing of the reference's source is copied: this script drives the reference's public classes
+the way ba.py:68-105 does (minus the viewer lines 79-81 and 103, whose dependencies are absent)
+and stores inputs + outputs as .npz.  Fixture names follow SURVEY.md section 8c (G1..G9).
+"""
+import argparse
+import io
+import os
+import runpy
+import sys
+import contextlib
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+
+
+def default_configs(**over):
+    cfg = dict(gauss_noise_std=2, loss=None, Nstds=3.0, beta=0.01, num_undamped_iters=6,
+               min_linear_iters=8, eta_damping=0.4, prior_std_weaker_factor=50.0)
+    cfg.update(over)
+    return cfg
+
+
+def beliefs_of(graph):
+    ce = np.array([n.belief.eta for n in graph.cam_nodes])
+    cl = np.array([n.belief.lam for n in graph.cam_nodes])
+    le = np.array([n.belief.eta for n in graph.lmk_nodes])
+    ll = np.array([n.belief.lam for n in graph.lmk_nodes])
+    cm = np.array([n.mu for n in graph.cam_nodes])
+    lm = np.array([n.mu for n in graph.lmk_nodes])
+    return dict(cam_eta=ce, cam_lam=cl, lmk_eta=le, lmk_lam=ll, cam_mu=cm, lmk_mu=lm)
+
+
+def factor_state_of(graph):
+    return dict(
+        msg_cam_eta=np.array([f.messages[0].eta for f in graph.factors]),
+        msg_cam_lam=np.array([f.messages[0].lam for f in graph.factors]),
+        msg_lmk_eta=np.array([f.messages[1].eta for f in graph.factors]),
+        msg_lmk_lam=np.array([f.messages[1].lam for f in graph.factors]),
+        eta_damping=np.array([f.eta_damping for f in graph.factors], dtype=np.float64),
+        iters_since_relin=np.array([f.iters_since_relin for f in graph.factors], dtype=np.int32),
+        linpoint=np.array([np.asarray(f.linpoint, dtype=np.float64) for f in graph.factors]),
+    )
+
+
+def replay(gbp_ba, bal_file, n_iters, checkpoints=(), factor_checkpoints=(), float_impl=False,
+           final_prior_std_weaker_factor=100.0, num_weakening_steps=5, diagnostics=True, **cfg_over):
+    """ba.py:68-105 without the viewer.  Checkpoint k = state after k sweeps."""
+    cfg = default_configs(**cfg_over)
+    graph = gbp_ba.create_ba_graph(bal_file, cfg)
+    graph.generate_priors_var(weaker_factor=cfg['prior_std_weaker_factor'])
+    graph.update_all_beliefs()
+    weakening = np.log10(final_prior_std_weaker_factor) / num_weakening_steps
+    out = {}
+    are, energy, relins = [], [], []
+    for i in range(n_iters):
+        if float_impl and (i + 1) % 2 == 0 and i < num_weakening_steps * 2:
+            graph.weaken_priors(weakening)
+        if i == 3 or i == 8:
+            for f in graph.factors:
+                f.iters_since_relin = 1
+        if diagnostics:
+            are.append(graph.are())
+            energy.append(graph.energy())
+        relins.append(sum(1 for f in graph.factors if f.iters_since_relin == 0))
+        graph.synchronous_iteration(robustify=True, local_relin=True)
+        k = i + 1
+        if k in checkpoints:
+            for name, arr in beliefs_of(graph).items():
+                out[f'it{k}_{name}'] = arr
+        if k in factor_checkpoints:
+            for name, arr in factor_state_of(graph).items():
+                out[f'it{k}_{name}'] = arr
+    out['are'] = np.array(are)
+    out['energy'] = np.array(energy)
+    out['n_relin'] = np.array(relins, dtype=np.int32)
+    return graph, out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def g1(ref):
+    from gbp.factors import reprojection
+    rng = np.random.default_rng(1234)
+    K = np.array([[517.306408, 0., 318.64304], [0., 516.469215, 255.313989], [0., 0., 1.]])
+    xs = []
+    while len(xs) < 256:
+        x = np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-1.5, 1.5, 3), rng.uniform(-2, 2, 3)])
+        from utils import lie_algebra
+        p = lie_algebra.so3exp(x[3:6]) @ x[6:9] + x[0:3]
+        if p[2] > 0.2:
+            xs.append(x)
+    xs = np.array(xs)
+    h = np.array([reprojection.meas_fn(x, K) for x in xs])
+    J = np.array([reprojection.jac_fn(x, K) for x in xs])
+    save('G1_reproj_fn', x=xs, K=K, h=h, J=J)
+
+
+def g2_g3(ref):
+    from gbp import gbp_ba
+    from utils import read_balfile
+    bal = os.path.join(HERE, 'data', 'fr1desk_vsmall.txt')
+    C, L, F, cam_means, lmk_means, meas, cids, lids, K = read_balfile.read_balfile(bal)
+    graph = gbp_ba.create_ba_graph(bal, default_configs())
+    save('G2_init_factors_vsmall',
+         n=np.array([C, L, F]), K=K, cam_means=cam_means, lmk_means=lmk_means, meas=meas,
+         file_cam_idx=np.array(cids, dtype=np.int32), file_lmk_idx=np.array(lids, dtype=np.int32),
+         factor_cam=np.array([f.adj_vIDs[0] for f in graph.factors], dtype=np.int32),
+         factor_lmk=np.array([f.adj_vIDs[1] - C for f in graph.factors], dtype=np.int32),
+         factor_meas=np.array([f.measurement for f in graph.factors]),
+         factor_eta=np.array([f.factor.eta for f in graph.factors]),
+         factor_lam=np.array([f.factor.lam for f in graph.factors]),
+         linpoint=np.array([f.linpoint for f in graph.factors]))
+    graph.generate_priors_var(weaker_factor=50.0)
+    graph.update_all_beliefs()
+    b = beliefs_of(graph)
+    save('G3_priors_vsmall',
+         cam_prior_lambda=np.array([n.prior.lam[0, 0] for n in graph.cam_nodes]),
+         lmk_prior_lambda=np.array([n.prior.lam[0, 0] for n in graph.lmk_nodes]),
+         cam_prior_eta=np.array([n.prior.eta for n in graph.cam_nodes]),
+         lmk_prior_eta=np.array([n.prior.eta for n in graph.lmk_nodes]),
+         cam_prior_lam=np.array([n.prior.lam for n in graph.cam_nodes]),
+         lmk_prior_lam=np.array([n.prior.lam for n in graph.lmk_nodes]),
+         are0=np.array(graph.are()), energy0=np.array(graph.energy()), **b)
+
+
+def g4(ref):
+    from gbp import gbp_ba
+    bal = os.path.join(HERE, 'data', 'fr1desk_vsmall.txt')
+    _, out = replay(gbp_ba, bal, 30, checkpoints=(1, 2, 5, 16, 30), factor_checkpoints=(1, 16))
+    save('G4_trace_vsmall', **out)
+
+
+def g5(ref):
+    from gbp import gbp_ba
+    bal = os.path.join(HERE, 'data', 'fr1desk_small.txt')
+    _, out = replay(gbp_ba, bal, 30, checkpoints=(10, 30))
+    save('G5_gate_small', **out)
+
+
+def g6(ref):
+    from gbp import gbp_ba
+    bal = os.path.join(HERE, 'data', 'fr1desk.txt')
+    _, out = replay(gbp_ba, bal, 5, checkpoints=(5,))
+    save('G6_fr1desk_5it', **out)
+
+
+def g7(ref):
+    from gbp import gbp_ba
+    bal = os.path.join(HERE, 'data', 'fr1desk_vsmall.txt')
+    arrays = {}
+    for loss in ('huber', 'constant'):
+        graph, out = replay(gbp_ba, bal, 5, checkpoints=(1, 5), loss=loss)
+        for k, v in out.items():
+            arrays[f'{loss}_{k}'] = v
+        arrays[f'{loss}_adaptive_var'] = np.array([f.adaptive_gauss_noise_var for f in graph.factors], dtype=np.float64)
+        arrays[f'{loss}_robust_flag'] = np.array([f.robust_flag for f in graph.factors], dtype=np.uint8)
+    graph, out = replay(gbp_ba, bal, 12, checkpoints=(2, 12), float_impl=True)
+    for k, v in out.items():
+        arrays[f'floatimpl_{k}'] = v
+    arrays['floatimpl_cam_prior_lambda'] = np.array([n.prior.lam[0, 0] for n in graph.cam_nodes])
+    save('G7_robust_vsmall', **arrays)
+
+
+def g8(ref):
+    arrays = {}
+    for tag, argv in (('n100d3', ['--n_varnodes', '100', '--dim', '3', '--n_iters', '20']), ('defaults', [])):
+        old_argv = sys.argv
+        sys.argv = ['ndim_posegraph.py'] + argv
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                g = runpy.run_path(os.path.join(ref, 'ndim_posegraph.py'), run_name='__main__')
+        finally:
+            sys.argv = old_argv
+        lines = [ln for ln in buf.getvalue().split('\n') if ln.startswith('Iteration')]
+        energy = np.array([float(ln.split('Energy')[1].split('//')[0]) for ln in lines])
+        dist = np.array([float(ln.split('MAP')[1]) for ln in lines])
+        arrays[f'{tag}_energy'] = energy
+        arrays[f'{tag}_dist'] = dist
+        arrays[f'{tag}_final_means'] = g['graph'].get_means()
+        arrays[f'{tag}_map_mu'] = g['mu']
+        arrays[f'{tag}_stdout'] = np.array(buf.getvalue())
+    save('G8_toy_linear', **arrays)
+
+
+def g9(ref):
+    from gbp import gbp_ba
+    sys.path.insert(0, REPO)
+    from gbp_amd.synthetic import make_synthetic, write_bal
+    prob = make_synthetic(n_cams=8, n_lmks=200, obs_per_lmk=5, seed=0)
+    with tempfile.TemporaryDirectory() as td:
+        bal = os.path.join(td, 'synthetic_mini.txt')
+        write_bal(prob, bal)
+        _, out = replay(gbp_ba, bal, 20, checkpoints=(1, 5, 20))
+    save('G9_synthetic_mini', K=prob.K, cam_means=prob.cam_means, lmk_means=prob.lmk_means,
+         meas=prob.meas, cam_idx=prob.cam_idx, lmk_idx=prob.lmk_idx, **out)
+
+
+ALL = dict(G1=g1, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reference', default='/root/reference')
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    sys.path.insert(0, args.reference)
+    import warnings
+    warnings.simplefilter('ignore', SyntaxWarning)
+    names = [s for s in args.only.split(',') if s] or list(ALL)
+    for n in names:
+        ALL[n](args.reference)
