@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- GBP iterations/s on the synthetic 500-cam x 100k-landmark x 1M-factor BA graph.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one FactorGraph.synchronous_iteration(robustify=True, local_relin=True) (gbp/gbp.py:86-92)
+over the whole graph, inputs resident in HBM.  N>1 shards the graph by landmark across ranks (one
+process per GPU) with one camera-partial all-gather (RCCL) per iteration; the total work is fixed, so
+scaling is "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
+
+
+def algorithmic_bytes(F, L, C):
+    """fp64, packed-symmetric, steady-state iteration."""
+    return F * 1072 + L * 168 + C * 480
+
+
+def cpu_baseline(problem, budget_s=20.0):
+    """Time the CPU oracle (oracle/gbp_oracle.c, a port of the reference's algorithm) on the same workload."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    o = oracle.OracleBA.from_problem(problem, threads=cores)
+    o.generate_priors_var(50.0)
+    o.update_all_beliefs()
+    t0 = time.perf_counter()
+    o.iterate(1)
+    first = time.perf_counter() - t0
+    n = int(max(1, min(20, (budget_s * 0.6) // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    o.iterate(n)
+    dt = (time.perf_counter() - t0) / n
+    # single-thread figure on a smaller slice of the budget
+    o.set_threads(1)
+    t0 = time.perf_counter()
+    o.iterate(1)
+    dt1 = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "iter/s", "cores": cores, "kind": "port",
+            "sample": f"{n} sweeps of the same 1M-factor graph after 1 warm-up sweep (OpenMP, {cores} threads)",
+            "value_1thread": 1.0 / dt1, "us_per_factor_iter_1thread": dt1 / problem.n_factors * 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--cams', type=int, default=500)
+    ap.add_argument('--lmks', type=int, default=100_000)
+    ap.add_argument('--obs', type=int, default=10)
+    ap.add_argument('--no-fused', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from gbp_amd.synthetic import make_synthetic
+    problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0)
+    F, L, C = problem.n_factors, problem.n_lmks, problem.n_cams
+
+    if world > 1:
+        import torch.distributed as dist
+        from gbp_amd.sharded import ShardedBA
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        graph = ShardedBA(problem, device=local_rank, fused=not args.no_fused)
+        barrier = dist.barrier
+    else:
+        from gbp_amd.engine import BAEngine
+        graph = BAEngine.from_problem(problem, device=local_rank, fused=not args.no_fused)
+        barrier = lambda: None
+    graph.generate_priors_var(50.0)
+    graph.update_all_beliefs()
+
+    graph.iterate(args.warmup)
+    graph.sync()
+    graph.set_kernel_timing(True)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    graph.iterate(args.steps)
+    graph.sync()
+    barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms, k_n, k_name = graph.kernel_timing()
+    graph.set_kernel_timing(False)
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    are = graph.are()
+    if rank == 0:
+        info = graph.info()
+        ms = dt / args.steps * 1e3
+        its = args.steps / dt
+        # roofline of the dominant kernel: algorithmic bytes one launch covers / its mean duration
+        F_local = graph.F
+        L_local = graph.L
+        if k_name == 'k_sweep_fused':
+            bytes_per_launch = algorithmic_bytes(F_local, L_local, C)
+        else:                               # k_factor: factor stage only (62 doubles read + 36 written per factor)
+            bytes_per_launch = F_local * 98 * 8
+        k_avg_ms = k_ms / max(k_n, 1)
+        achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_n else 0.0
+        out = {
+            "metric": "GBP iterations/sec (whole node), 1M-factor BA graph",
+            "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic BAL {C} cams x {L} landmarks x {F} reprojection factors "
+                                   f"(gbp_amd.synthetic.make_synthetic seed 0), ba.py defaults, loss=None",
+                       "n_cams": C, "n_lmks": L, "n_factors": F,
+                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
+                       "sweep": "fused" if info['fused'] else "general"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": k_name, "kernel_avg_ms": k_avg_ms, "kernel_launches": k_n,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "whole_iteration_frac": algorithmic_bytes(F, L, C) * its / world / 1e9 / HBM_PEAK_GBS},
+            "are_after": are,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(problem)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,120 @@
+"""ctypes binding of include/gbp_ba.h (libgbp_hip.so).  Loading fails loudly: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgbp_hip.so')
+
+_dp = ct.POINTER(ct.c_double)
+_ip = ct.POINTER(ct.c_int32)
+_bp = ct.POINTER(ct.c_uint8)
+
+LOSS = {None: 0, 'None': 0, 'none': 0, 'huber': 1, 'constant': 2}
+FLAG_NO_FUSED = 1
+CAM_PARTIAL_DOUBLES = 27
+
+
+class Desc(ct.Structure):
+    _fields_ = [('n_cams', ct.c_int32), ('n_lmks', ct.c_int32), ('n_factors', ct.c_int32), ('device', ct.c_int32),
+                ('K', ct.c_double * 4),
+                ('cam_means', _dp), ('lmk_means', _dp), ('meas', _dp), ('cam_idx', _ip), ('lmk_idx', _ip),
+                ('gauss_noise_std', ct.c_double),
+                ('loss', ct.c_int32), ('num_undamped_iters', ct.c_int32), ('min_linear_iters', ct.c_int32),
+                ('flags', ct.c_int32),
+                ('nstds', ct.c_double), ('beta', ct.c_double), ('eta_damping', ct.c_double)]
+
+
+class GbpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgbp_hip error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/gbp_ba.h declares: (restype, argtypes)
+SIGNATURES = {
+    'gbp_abi_version': (ct.c_int, []),
+    'gbp_last_error': (ct.c_char_p, []),
+    'gbp_ba_create': (ct.c_int, [ct.POINTER(ct.c_void_p), ct.POINTER(Desc)]),
+    'gbp_ba_destroy': (None, [ct.c_void_p]),
+    'gbp_ba_set_stream': (ct.c_int, [ct.c_void_p, ct.c_void_p]),
+    'gbp_ba_sync': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_generate_priors': (ct.c_int, [ct.c_void_p, ct.c_double]),
+    'gbp_ba_factor_lambda_max': (ct.c_int, [ct.c_void_p, _dp, _dp]),
+    'gbp_ba_set_prior_scalars': (ct.c_int, [ct.c_void_p, _dp, _dp]),
+    'gbp_ba_set_priors': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
+    'gbp_ba_weaken_priors': (ct.c_int, [ct.c_void_p, ct.c_double]),
+    'gbp_ba_update_beliefs': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_iterate': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
+    'gbp_ba_are': (ct.c_int, [ct.c_void_p, _dp]),
+    'gbp_ba_energy': (ct.c_int, [ct.c_void_p, _dp]),
+    'gbp_ba_residual_sums': (ct.c_int, [ct.c_void_p, _dp]),
+    'gbp_ba_get_beliefs': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
+    'gbp_ba_get_means': (ct.c_int, [ct.c_void_p, _dp, _dp]),
+    'gbp_ba_get_covariances': (ct.c_int, [ct.c_void_p, _dp, _dp]),
+    'gbp_ba_get_priors': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
+    'gbp_ba_get_messages': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, _dp, _dp, _dp, _dp]),
+    'gbp_ba_get_factors': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, _dp, _dp, _dp, _ip, _ip, _dp]),
+    'gbp_ba_get_relin_state': (ct.c_int, [ct.c_void_p, _ip, _dp, _dp, _bp]),
+    'gbp_ba_set_iters_since_relin': (ct.c_int, [ct.c_void_p, _ip]),
+    'gbp_ba_fill_iters_since_relin': (ct.c_int, [ct.c_void_p, ct.c_int32]),
+    'gbp_ba_shard_begin': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_void_p]),
+    'gbp_ba_shard_end': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32]),
+    'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),
+    'gbp_ba_get_kernel_timing': (ct.c_int, [ct.c_void_p, _dp, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_char_p)]),
+    'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libgbp_hip.so and bind every declared symbol (AttributeError if one is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m gbp_amd.build` "
+                              f"(hipcc --offload-arch=gfx950).  gbp_amd has no CPU fallback.")
+        lib = ct.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gbp_abi_version() != 1:
+            raise ImportError(f"libgbp_hip.so ABI {lib.gbp_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GbpError(rc, load().gbp_last_error().decode('utf-8', 'replace'))
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def bptr(a):
+    return None if a is None else a.ctypes.data_as(_bp)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def i32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a

@@ -1,0 +1,45 @@
+"""Build libgbp_hip.so (the HIP kernels + C ABI) for gfx950, in-tree, with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so ships
+to the GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libgbp_hip.so')
+SOURCES = ['gbp_capi.hip']
+DEPS = ['gbp_capi.hip', 'gbp_kernels.hpp', 'gbp_fused.hpp', 'gbp_math.hpp', os.path.join('..', '..', 'include', 'gbp_ba.h')]
+
+
+def hipcc_path():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libgbp_hip.so cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-ffp-contract=fast', '-o', LIB] + SOURCES
+    if verbose:
+        cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True))

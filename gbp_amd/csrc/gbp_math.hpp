@@ -1,0 +1,322 @@
+// gbp_math.hpp -- per-factor / per-variable fp64 device maths of the GBP bundle-adjustment sweep.
+//
+// Everything here runs in ONE LANE per factor (or per variable) with all state in VGPRs: every
+// loop has compile-time bounds and is fully unrolled so no array is ever indexed at run time.
+// fp64 throughout (fp32 storage or arithmetic cannot meet the 1e-4 gate).
+//
+// Reference maths restated (file:line of joeaortiz/gbp):
+//   pin-hole projection + 2x9 Jacobian   gbp/factors/reprojection.py:12-44, utils/derivatives.py:36-50,
+//                                        utils/lie_algebra.py:11-42, utils/transformations.py:5-7
+//   linearisation  Lambda_f, eta_f       gbp/gbp.py:278-289
+//   robust re-weighting                  gbp/gbp.py:296-332
+//   relinearisation test                 gbp/gbp.py:70-80
+//   factor->variable messages            gbp/gbp.py:334-373
+//   belief = prior + sum(messages)       gbp/gbp.py:176-198
+//
+// Algebraic restructuring (same maths, fewer bytes and flops than the dense reference):
+//   * Lambda_f = s J^T J is never materialised: with J = [Jc | Jl] (2x6 | 2x3) and rho = J x0 + z - h,
+//       A = s Jc^T Jc, B = s Jc^T Jl, Cc = s Jl^T Jl, a = s Jc^T rho, c = s Jl^T rho.
+//   * message to the camera   M' = A - B S^-1 B^T  with S = Cc + (Lambda_L - M_L)  becomes
+//       M' = Jc^T (s I - s^2 Jl S^-1 Jl^T) Jc,   e* = s Jc^T (rho - Jl S^-1 g),  g = c + eta_L - e_L
+//     and symmetrically for the landmark with the 6x6 T = A + (Lambda_C - M_C).
+//   * S and T are symmetric positive definite (factor block + cavity >= prior), so the general LU
+//     inverse of the reference is replaced by an unpivoted LDL^T on packed upper storage, and only
+//     the forward substitution is needed: X^T S^-1 Y = (L^-1 X)^T D^-1 (L^-1 Y).
+//   * symmetric matrices are stored packed (upper triangle, row-major): 6x6 -> 21, 3x3 -> 6.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gbp {
+
+#define GBP_DEV __device__ __forceinline__
+
+template <int N>
+struct Sym {
+    static constexpr int size = N * (N + 1) / 2;
+    // packed index of (i, j), i <= j
+    static constexpr __host__ __device__ int at(int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }
+};
+
+struct Intrinsics {
+    double fx, fy, cx, cy;
+};
+
+// In-place LDL^T of a packed SPD matrix: on exit the diagonal holds D, the strict upper part holds
+// U = L^T (unit upper), invd[k] = 1/D_k.
+template <int N>
+GBP_DEV void ldl_factor(double (&a)[Sym<N>::size], double (&invd)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double r = 1.0 / a[Sym<N>::at(k, k)];
+        invd[k] = r;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const double u = a[Sym<N>::at(k, i)] * r;
+#pragma unroll
+            for (int j = i; j < N; ++j) a[Sym<N>::at(i, j)] -= u * a[Sym<N>::at(k, j)];
+            a[Sym<N>::at(k, i)] = u;
+        }
+    }
+}
+
+// b <- L^-1 b  (unit lower L = U^T from ldl_factor)
+template <int N>
+GBP_DEV void ldl_forward(const double (&a)[Sym<N>::size], double (&b)[N])
+{
+#pragma unroll
+    for (int i = 1; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) b[i] -= a[Sym<N>::at(k, i)] * b[k];
+}
+
+// b <- L^-T b
+template <int N>
+GBP_DEV void ldl_backward(const double (&a)[Sym<N>::size], double (&b)[N])
+{
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i)
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) b[i] -= a[Sym<N>::at(i, k)] * b[k];
+}
+
+// mu = Lambda^-1 eta for a packed SPD Lambda (VariableNode.update_belief gbp.py:192-193, and the
+// belief means of gbp.py:74).  Lambda is consumed.
+template <int N>
+GBP_DEV void spd_solve(double (&lam)[Sym<N>::size], const double (&eta)[N], double (&mu)[N])
+{
+    double invd[N];
+    ldl_factor<N>(lam, invd);
+#pragma unroll
+    for (int i = 0; i < N; ++i) mu[i] = eta[i];
+    ldl_forward<N>(lam, mu);
+#pragma unroll
+    for (int i = 0; i < N; ++i) mu[i] *= invd[i];
+    ldl_backward<N>(lam, mu);
+}
+
+// Sigma = Lambda^-1 (packed) from the LDL^T factors; used only by the covariance view.
+template <int N>
+GBP_DEV void spd_inverse(double (&lam)[Sym<N>::size], double (&sig)[Sym<N>::size])
+{
+    double invd[N];
+    ldl_factor<N>(lam, invd);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        double e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = (i == c) ? 1.0 : 0.0;
+        ldl_forward<N>(lam, e);
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] *= invd[i];
+        ldl_backward<N>(lam, e);
+#pragma unroll
+        for (int i = 0; i <= c; ++i) sig[Sym<N>::at(i, c)] = e[i];
+    }
+}
+
+// Rodrigues rotation of the axis-angle w (utils/lie_algebra.py:32-42) plus the three scalars the
+// Jacobian of R(w) y needs.  Below 3*eps the reference returns R = I and its dR_wx_dw formula
+// degenerates to -y^ (w w^T)/(w.w): mirrored through (c1, cI, cW) = (1/theta^2, 0, 0).
+struct Rot {
+    double r[3][3];
+    double c1, cI, cW;   // (R^T - I) w^ + w w^T  ==  theta^2 * (c1 w w^T + cI I - cW w^)
+};
+
+GBP_DEV Rot rodrigues(double w0, double w1, double w2)
+{
+    Rot o;
+    const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    const double th = sqrt(th2);
+    if (th < 3.0 * 2.220446049250313e-16) {
+        o.r[0][0] = 1.0; o.r[0][1] = 0.0; o.r[0][2] = 0.0;
+        o.r[1][0] = 0.0; o.r[1][1] = 1.0; o.r[1][2] = 0.0;
+        o.r[2][0] = 0.0; o.r[2][1] = 0.0; o.r[2][2] = 1.0;
+        o.c1 = 1.0 / th2; o.cI = 0.0; o.cW = 0.0;
+        return o;
+    }
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const double ith2 = 1.0 / th2;
+    const double a = sn / th;
+    const double b = (1.0 - cs) * ith2;
+    // R = I + a w^ + b w^ w^,  w^ w^ = w w^T - theta^2 I  (diagonal written without cancellation)
+    o.r[0][0] = 1.0 - b * (w1 * w1 + w2 * w2);
+    o.r[1][1] = 1.0 - b * (w0 * w0 + w2 * w2);
+    o.r[2][2] = 1.0 - b * (w0 * w0 + w1 * w1);
+    const double b01 = b * w0 * w1, b02 = b * w0 * w2, b12 = b * w1 * w2;
+    o.r[0][1] = b01 - a * w2; o.r[1][0] = b01 + a * w2;
+    o.r[0][2] = b02 + a * w1; o.r[2][0] = b02 - a * w1;
+    o.r[1][2] = b12 - a * w0; o.r[2][1] = b12 + a * w0;
+    o.c1 = (1.0 - a) * ith2; o.cI = a; o.cW = b;
+    return o;
+}
+
+// h(x) = proj(K (R(w) y + t))   reprojection.py:12-24
+GBP_DEV void project(const double (&x)[9], const Intrinsics &K, double (&h)[2])
+{
+    const Rot R = rodrigues(x[3], x[4], x[5]);
+    const double p0 = R.r[0][0] * x[6] + R.r[0][1] * x[7] + R.r[0][2] * x[8] + x[0];
+    const double p1 = R.r[1][0] * x[6] + R.r[1][1] * x[7] + R.r[1][2] * x[8] + x[1];
+    const double p2 = R.r[2][0] * x[6] + R.r[2][1] * x[7] + R.r[2][2] * x[8] + x[2];
+    const double iz = 1.0 / p2;
+    h[0] = (K.fx * p0 + K.cx * p2) * iz;
+    h[1] = (K.fy * p1 + K.cy * p2) * iz;
+}
+
+// h(x) and J(x) = [J_p K | J_p K dR_wx_dw(w, y) | J_p K R]   reprojection.py:27-44
+GBP_DEV void linearise(const double (&x)[9], const Intrinsics &K, double (&Jc)[2][6], double (&Jl)[2][3],
+                       double (&h)[2])
+{
+    const double w0 = x[3], w1 = x[4], w2 = x[5], y0 = x[6], y1 = x[7], y2 = x[8];
+    const Rot R = rodrigues(w0, w1, w2);
+    const double p0 = R.r[0][0] * y0 + R.r[0][1] * y1 + R.r[0][2] * y2 + x[0];
+    const double p1 = R.r[1][0] * y0 + R.r[1][1] * y1 + R.r[1][2] * y2 + x[1];
+    const double p2 = R.r[2][0] * y0 + R.r[2][1] * y1 + R.r[2][2] * y2 + x[2];
+    const double iz = 1.0 / p2;
+    h[0] = (K.fx * p0 + K.cx * p2) * iz;
+    h[1] = (K.fy * p1 + K.cy * p2) * iz;
+    // J_p K = [[fx/Z, 0, cx/Z - X/Z^2], [0, fy/Z, cy/Z - Y/Z^2]];  cx/Z - X/Z^2 == -fx p0 / Z^2
+    const double a0 = K.fx * iz, a2 = -a0 * p0 * iz;
+    const double b1 = K.fy * iz, b2 = -b1 * p1 * iz;
+    Jc[0][0] = a0;  Jc[0][1] = 0.0; Jc[0][2] = a2;
+    Jc[1][0] = 0.0; Jc[1][1] = b1;  Jc[1][2] = b2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Jl[0][j] = a0 * R.r[0][j] + a2 * R.r[2][j];
+        Jl[1][j] = b1 * R.r[1][j] + b2 * R.r[2][j];
+    }
+    // J_p K dR_wx_dw = -(J_p K R) y^ (c1 w w^T + cI I - cW w^)      derivatives.py:36-45
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double q0 = Jl[r][1] * y2 - Jl[r][2] * y1;
+        const double q1 = Jl[r][2] * y0 - Jl[r][0] * y2;
+        const double q2 = Jl[r][0] * y1 - Jl[r][1] * y0;
+        const double qw = (q0 * w0 + q1 * w1 + q2 * w2) * R.c1;
+        Jc[r][3] = -(qw * w0 + R.cI * q0 - R.cW * (q1 * w2 - q2 * w1));
+        Jc[r][4] = -(qw * w1 + R.cI * q1 - R.cW * (q2 * w0 - q0 * w2));
+        Jc[r][5] = -(qw * w2 + R.cI * q2 - R.cW * (q0 * w1 - q1 * w0));
+    }
+}
+
+// Factor.robustify_loss: adaptive noise variance from the residual AT THE LINEARISATION POINT
+// (gbp.py:309-328).  loss: 1 huber, 2 constant ("m^2" without sigma^2 is the reference's, gbp.py:324).
+GBP_DEV double robust_variance(int loss, double sigma2, double nstds, double r0, double r1, bool &flag)
+{
+    const double m = sqrt(r0 * r0 + r1 * r1) / sqrt(sigma2);
+    flag = m > nstds;
+    if (!flag) return sigma2;
+    if (loss == 1) return sigma2 * (m * m) / (2.0 * (nstds * m - 0.5 * (nstds * nstds)));
+    return m * m;
+}
+
+// One factor's two outgoing messages (Factor.compute_messages gbp.py:334-373, BA-specialised).
+//   in : Jc, Jl, rho, s = 1/adaptive_var, damping d,
+//        camera belief (etaC 6, lamC 21), landmark belief (etaL 3, lamL 6),
+//        old messages: to camera (eC 6, MC 21), to landmark (eL 3, ML 6)
+//   out: eC/MC and eL/ML are overwritten with the new messages (both computed from the OLD ones,
+//        committed together: gbp.py:371-373).
+GBP_DEV void factor_messages(const double (&Jc)[2][6], const double (&Jl)[2][3], const double (&rho)[2],
+                             double s, double d,
+                             const double (&etaC)[6], const double (&lamC)[21],
+                             const double (&etaL)[3], const double (&lamL)[6],
+                             double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6])
+{
+    double newMC[21], neweC[6];
+    {   // ---- to the camera: eliminate the landmark (3x3) -------------------------------------
+        double S[6], g[3], invd[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            g[i] = s * (Jl[0][i] * rho[0] + Jl[1][i] * rho[1]) + (etaL[i] - eL[i]);
+#pragma unroll
+            for (int j = i; j < 3; ++j)
+                S[Sym<3>::at(i, j)] = s * (Jl[0][i] * Jl[0][j] + Jl[1][i] * Jl[1][j]) +
+                                      (lamL[Sym<3>::at(i, j)] - ML[Sym<3>::at(i, j)]);
+        }
+        ldl_factor<3>(S, invd);
+        double y0[3], y1[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { y0[i] = Jl[0][i]; y1[i] = Jl[1][i]; }
+        ldl_forward<3>(S, y0); ldl_forward<3>(S, y1); ldl_forward<3>(S, g);
+        double G00 = 0.0, G01 = 0.0, G11 = 0.0, k0 = 0.0, k1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double t0 = y0[i] * invd[i], t1 = y1[i] * invd[i];
+            G00 += t0 * y0[i]; G01 += t0 * y1[i]; G11 += t1 * y1[i];
+            k0 += t0 * g[i]; k1 += t1 * g[i];
+        }
+        const double W00 = s - s * s * G00, W01 = -(s * s) * G01, W11 = s - s * s * G11;
+        const double r0 = s * (rho[0] - k0), r1 = s * (rho[1] - k1);
+        double WJ0[6], WJ1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            WJ0[j] = W00 * Jc[0][j] + W01 * Jc[1][j];
+            WJ1[j] = W01 * Jc[0][j] + W11 * Jc[1][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            neweC[i] = (1.0 - d) * (Jc[0][i] * r0 + Jc[1][i] * r1) + d * eC[i];
+#pragma unroll
+            for (int j = i; j < 6; ++j) newMC[Sym<6>::at(i, j)] = Jc[0][i] * WJ0[j] + Jc[1][i] * WJ1[j];
+        }
+    }
+    {   // ---- to the landmark: eliminate the camera (6x6) --------------------------------------
+        double T[21], u[6], invd[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            u[i] = s * (Jc[0][i] * rho[0] + Jc[1][i] * rho[1]) + (etaC[i] - eC[i]);
+#pragma unroll
+            for (int j = i; j < 6; ++j)
+                T[Sym<6>::at(i, j)] = s * (Jc[0][i] * Jc[0][j] + Jc[1][i] * Jc[1][j]) +
+                                      (lamC[Sym<6>::at(i, j)] - MC[Sym<6>::at(i, j)]);
+        }
+        ldl_factor<6>(T, invd);
+        double y0[6], y1[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { y0[i] = Jc[0][i]; y1[i] = Jc[1][i]; }
+        ldl_forward<6>(T, y0); ldl_forward<6>(T, y1); ldl_forward<6>(T, u);
+        double H00 = 0.0, H01 = 0.0, H11 = 0.0, k0 = 0.0, k1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double t0 = y0[i] * invd[i], t1 = y1[i] * invd[i];
+            H00 += t0 * y0[i]; H01 += t0 * y1[i]; H11 += t1 * y1[i];
+            k0 += t0 * u[i]; k1 += t1 * u[i];
+        }
+        const double V00 = s - s * s * H00, V01 = -(s * s) * H01, V11 = s - s * s * H11;
+        const double r0 = s * (rho[0] - k0), r1 = s * (rho[1] - k1);
+        double VJ0[3], VJ1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            VJ0[j] = V00 * Jl[0][j] + V01 * Jl[1][j];
+            VJ1[j] = V01 * Jl[0][j] + V11 * Jl[1][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            eL[i] = (1.0 - d) * (Jl[0][i] * r0 + Jl[1][i] * r1) + d * eL[i];
+#pragma unroll
+            for (int j = i; j < 3; ++j) ML[Sym<3>::at(i, j)] = Jl[0][i] * VJ0[j] + Jl[1][i] * VJ1[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) eC[i] = neweC[i];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) MC[i] = newMC[i];
+}
+
+// max over all 81 signed entries of Lambda_f = s J^T J (np.max(factor.factor.lam), gbp_ba.py:31)
+GBP_DEV double factor_lambda_max(const double (&Jc)[2][6], const double (&Jl)[2][3], double s)
+{
+    double J0[9], J1[9];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { J0[i] = Jc[0][i]; J1[i] = Jc[1][i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { J0[6 + i] = Jl[0][i]; J1[6 + i] = Jl[1][i]; }
+    double m = s * (J0[0] * J0[0] + J1[0] * J1[0]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = i; j < 9; ++j) m = fmax(m, s * (J0[i] * J0[j] + J1[i] * J1[j]));
+    return m;
+}
+
+}  // namespace gbp

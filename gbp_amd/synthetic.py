@@ -112,6 +112,7 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
     chosen = np.empty((n_lmks, obs_per_lmk), dtype=np.int32)
     done = 0
     chunk = 8192
+    stalls = 0
     while done < n_lmks:
         m = min(chunk, n_lmks - done)
         v = rng.normal(size=(m, 3))
@@ -128,6 +129,9 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
         good = np.take_along_axis(keys, pick, axis=1).max(axis=1) < 1.5
         k = int(good.sum())
         k = min(k, n_lmks - done)
+        stalls = stalls + 1 if k == 0 else 0
+        if stalls > 50:
+            raise ValueError(f"no landmark is visible from {obs_per_lmk} of the {n_cams} cameras")
         sel = np.nonzero(good)[0][:k]
         lmk[done:done + k] = pts[sel]
         chosen[done:done + k] = np.sort(pick[sel], axis=1)

@@ -1,0 +1,127 @@
+/*
+ * gbp_ba.h -- C ABI of libgbp_hip.so: the GBP bundle-adjustment sweep on MI355X (gfx950).
+ *
+ * The reference (joeaortiz/gbp) is pure Python and has no FFI/plugin interface; its "operator
+ * boundary" for this path is the Python class API that ba.py drives.  Each
+ * entry point below replaces the reference method cited next to it; gbp_amd/compat/ re-exposes
+ * them under the reference's class and method names through ctypes.
+ *
+ * Conventions
+ *  - every call returns 0 on success or a negative GBP_E* code; gbp_last_error() gives the
+ *    thread-local message.  No exception or abort() crosses the boundary.
+ *  - all host pointers are caller-owned, contiguous, C-order float64 / int32; the library copies
+ *    in and out and never retains them.  Pointers named *_dev are DEVICE pointers (sharded mode).
+ *  - factor-indexed arrays at the boundary are in the REFERENCE's factor order: camera-major,
+ *    file order inside a camera (gbp/gbp_ba.py:128-130).  Variables: cameras 0..C-1 then
+ *    landmarks 0..L-1 (gbp/gbp_ba.py:114-125).  The internal layout (landmark-major SoA) is
+ *    never visible.
+ *  - dense matrices are row-major; beliefs/messages/priors are information form (eta, Lambda).
+ *  - one host thread per handle; calls that return data synchronise the handle's stream.
+ */
+#ifndef GBP_BA_H
+#define GBP_BA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBP_ABI_VERSION 1
+
+enum {
+    GBP_OK = 0,
+    GBP_EINVAL = -1,   /* bad argument / index out of range */
+    GBP_ENOMEM = -2,   /* host or device allocation failed */
+    GBP_EHIP = -3,     /* a HIP runtime call failed (message has the HIP error string) */
+    GBP_ENODEV = -4,   /* no usable gfx950 device */
+    GBP_ESTATE = -5    /* call not valid in the handle's current state */
+};
+
+enum { GBP_LOSS_NONE = 0, GBP_LOSS_HUBER = 1, GBP_LOSS_CONSTANT = 2 };   /* Factor.loss, gbp/gbp.py:243 */
+
+typedef struct gbp_ba gbp_ba_t;
+
+/* What create_ba_graph(bal_file, configs) consumes (gbp/gbp_ba.py:97-107,134-135), as arrays.
+ * Observations are given in FILE order; the library applies the reference's camera-major order. */
+typedef struct gbp_ba_desc {
+    int32_t n_cams;               /* C */
+    int32_t n_lmks;               /* L */
+    int32_t n_factors;            /* F */
+    int32_t device;               /* HIP device ordinal */
+    double K[4];                  /* fx fy cx cy            utils/read_balfile.py:14-16 */
+    const double *cam_means;      /* C*6  t(3), axis-angle(3)   gbp_ba.py:116 */
+    const double *lmk_means;      /* L*3                        gbp_ba.py:123 */
+    const double *meas;           /* F*2 pixels                 gbp_ba.py:134 */
+    const int32_t *cam_idx;       /* F                          read_balfile.py:21 */
+    const int32_t *lmk_idx;       /* F                          read_balfile.py:22 */
+    double gauss_noise_std;       /* configs['gauss_noise_std'] gbp_ba.py:135 */
+    int32_t loss;                 /* GBP_LOSS_*                 configs['loss'] */
+    int32_t num_undamped_iters;   /* gbp/gbp.py:33 */
+    int32_t min_linear_iters;     /* gbp/gbp.py:34 */
+    int32_t flags;                /* GBP_FLAG_* */
+    double nstds;                 /* configs['Nstds'] -> mahalanobis_threshold gbp.py:244 */
+    double beta;                  /* gbp/gbp.py:32 */
+    double eta_damping;           /* gbp/gbp.py:28 */
+} gbp_ba_desc_t;
+
+#define GBP_FLAG_NO_FUSED 1       /* force the general 3-kernel sweep (testing / ablation) */
+
+int gbp_abi_version(void);
+const char *gbp_last_error(void);
+
+/* life cycle: create_ba_graph incl. the initial compute_factor of every factor (gbp_ba.py:97-150) */
+int gbp_ba_create(gbp_ba_t **out, const gbp_ba_desc_t *desc);
+void gbp_ba_destroy(gbp_ba_t *h);
+int gbp_ba_set_stream(gbp_ba_t *h, void *hip_stream);     /* NULL = the handle's own stream */
+int gbp_ba_sync(gbp_ba_t *h);
+
+/* priors */
+int gbp_ba_generate_priors(gbp_ba_t *h, double weaker_factor);          /* BAFactorGraph.generate_priors_var gbp_ba.py:20-34 */
+int gbp_ba_factor_lambda_max(gbp_ba_t *h, double *cam_max, double *lmk_max);  /* the max_f max(Lambda_f) half of it (sharded set-up) */
+int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double *lmk_lambda); /* Lambda=l*I, eta=l*mu  gbp_ba.py:32-34 */
+int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam,
+                      const double *lmk_eta, const double *lmk_lam);    /* information form; serves set_priors_var gbp_ba.py:44-52 */
+int gbp_ba_weaken_priors(gbp_ba_t *h, double factor);                   /* BAFactorGraph.weaken_priors gbp_ba.py:36-42 */
+
+/* the sweep */
+int gbp_ba_update_beliefs(gbp_ba_t *h);                                 /* FactorGraph.update_all_beliefs gbp.py:56-58 */
+int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin);
+                                                                        /* n x FactorGraph.synchronous_iteration gbp.py:86-92 */
+
+/* diagnostics ba.py prints every iteration */
+int gbp_ba_are(gbp_ba_t *h, double *out);                               /* BAFactorGraph.are gbp_ba.py:61-69 */
+int gbp_ba_energy(gbp_ba_t *h, double *out);                            /* FactorGraph.energy gbp.py:36-44 */
+int gbp_ba_residual_sums(gbp_ba_t *h, double out[2]);                   /* {sum ||r||, sum 0.5||r||^2/var}: un-normalised, for shards */
+
+/* state views (reference order, dense); any pointer may be NULL to skip that array */
+int gbp_ba_get_beliefs(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam);  /* VariableNode.belief gbp.py:168 */
+int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu);                                        /* VariableNode.mu gbp.py:165,193 */
+int gbp_ba_get_covariances(gbp_ba_t *h, double *cam_sigma, double *lmk_sigma);                            /* VariableNode.Sigma gbp.py:166,192 */
+int gbp_ba_get_priors(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam);   /* VariableNode.prior gbp.py:170 */
+int gbp_ba_get_messages(gbp_ba_t *h, int32_t f0, int32_t n, double *cam_eta, double *cam_lam,
+                        double *lmk_eta, double *lmk_lam);                                                /* Factor.messages gbp.py:222 */
+int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *lam, double *linpoint,
+                       int32_t *cam, int32_t *lmk, double *meas);                                         /* Factor.factor/.linpoint/.adj_vIDs gbp.py:230-233 */
+int gbp_ba_get_relin_state(gbp_ba_t *h, int32_t *iters_since_relin, double *eta_damping,
+                           double *adaptive_var, uint8_t *robust_flag);                                   /* gbp.py:242-249 */
+int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters);                                      /* ba.py:91-93 (per factor) */
+int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value);                                            /* ba.py:91-93 (all factors) */
+
+/* landmark-sharded multi-GPU sweep (no reference counterpart).  Each rank owns a
+ * landmark range and its factors, cameras are replicated.  begin = (if with_messages) robustify /
+ * relinearise / messages, then landmark beliefs + this rank's camera partial sums (C*27 packed doubles: eta 6, upper Lambda 21) into
+ * partial_dev; the caller all-gathers; end = fixed rank-order sum + prior + camera beliefs. */
+int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, int32_t local_relin, double *partial_dev);
+int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks);
+#define GBP_CAM_PARTIAL_DOUBLES 27
+
+/* instrumentation for bench.py: HIP-event time of the dominant (factor) kernel on the handle's stream */
+int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
+int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);
+int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBP_BA_H */

@@ -1,0 +1,68 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads, exports every symbol
+include/gbp_ba.h declares, and refuses to run without a GPU (no CPU fallback in the product path)."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from gbp_amd import build, _capi
+    build.build()
+    return _capi
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'gbp_ba.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gbp_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_symbols_all_exported_and_bound(capi):
+    lib = capi.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gbp_ba.h but not exported by libgbp_hip.so"
+    assert set(names) == set(capi.SIGNATURES), set(names) ^ set(capi.SIGNATURES)
+    assert lib.gbp_abi_version() == 1
+
+
+def test_desc_struct_matches_header_layout(capi):
+    # 4 int32, 4 doubles, 5 pointers, 1 double, 4 int32, 3 doubles on LP64
+    assert ct.sizeof(capi.Desc) == 16 + 32 + 40 + 8 + 16 + 24
+
+
+def test_product_path_has_no_cpu_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from gbp_amd.engine import BAEngine
+    with pytest.raises(capi.GbpError) as ei:
+        BAEngine([500., 500., 320., 240.], np.zeros((1, 6)), np.zeros((1, 3)), np.zeros((1, 2)), [0], [0])
+    assert ei.value.code == -4 and 'no CPU path' in str(ei.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, 'gbp_amd')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.cpp', '.h')):
+                src = open(os.path.join(root, f)).read()
+                assert 'oracle' not in src.replace('gbp_oracle.c header', ''), f"{f} mentions the oracle"
+
+
+def test_bad_arguments_are_reported_not_crashed(capi):
+    lib = capi.load()
+    h = ct.c_void_p()
+    assert lib.gbp_ba_create(ct.byref(h), None) == -1
+    d = capi.Desc()
+    d.n_factors = -1
+    assert lib.gbp_ba_create(ct.byref(h), ct.byref(d)) == -1
+    assert b'negative' in lib.gbp_last_error()
+    assert lib.gbp_ba_iterate(None, 1, 1, 1) == -1

@@ -1,0 +1,286 @@
+"""GPU parity: the HIP engine (through the C ABI) against the golden fixtures generated from the
+reference and against the CPU oracle on the same seeded inputs.
+
+Tolerance: BASELINE.json north_star asks for beliefs (eta, Lambda) within 1e-4 relative of the
+reference.  The sweep amplifies fp64 rounding by ~1e6..1e7 (oracle-vs-reference is already 1e-9..2e-8),
+so the asserted bound is 1e-6 on beliefs -- two orders inside the gate -- and 1e-5 on messages.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, belief_gap, golden, rel_err_rows
+from gbp_amd.balio import read_bal
+from gbp_amd.synthetic import BAProblem, make_synthetic
+
+pytestmark = pytest.mark.gpu
+
+BELIEF_TOL = 1e-6
+MSG_TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def eng_mod():
+    from gbp_amd import engine
+    return engine
+
+
+def make(eng_mod, name, **kw):
+    p = read_bal(os.path.join(DATA, name))
+    e = eng_mod.BAEngine.from_problem(p, **kw)
+    e.generate_priors_var(50.0)
+    e.update_all_beliefs()
+    return p, e
+
+
+def replay_with_snaps(oracle_mod, e, n_sweeps, checkpoints, **kw):
+    snaps, relin = {}, []
+
+    def grab(i, graph):
+        st = graph.relin_state()
+        relin.append(int((st['iters_since_relin'] == 0).sum()))
+        if i in checkpoints:
+            snaps[i] = dict(bel=graph.beliefs(), mu=graph.means(), msg=graph.messages(), st=st)
+    ares, energies = oracle_mod.replay_ba(e, n_sweeps + 1, diagnostics=True, on_iter=grab, **kw)
+    return ares[:n_sweeps], energies[:n_sweeps], np.array(relin[:n_sweeps]), snaps
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g2_initial_factors(eng_mod, fused):
+    g = golden('G2_init_factors_vsmall')
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    e = eng_mod.BAEngine.from_problem(p, fused=fused)
+    f = e.factors()
+    assert np.array_equal(f['cam'], g['factor_cam']) and np.array_equal(f['lmk'], g['factor_lmk'])
+    assert np.array_equal(f['z'], g['factor_meas'])
+    assert np.array_equal(f['linpoint'], g['linpoint'])
+    assert rel_err_rows(f['eta'], g['factor_eta']) < 1e-10
+    assert rel_err_rows(f['lam'], g['factor_lam']) < 1e-10
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g3_priors_and_first_beliefs(eng_mod, fused):
+    g = golden('G3_priors_vsmall')
+    _, e = make(eng_mod, 'fr1desk_vsmall.txt', fused=fused)
+    pce, pcl, ple, pll = e.priors()
+    assert np.allclose(pcl[:, 0, 0], g['cam_prior_lambda'], rtol=1e-10)
+    assert np.allclose(pll[:, 0, 0], g['lmk_prior_lambda'], rtol=1e-10)
+    assert rel_err_rows(pce, g['cam_prior_eta']) < 1e-10 and rel_err_rows(ple, g['lmk_prior_eta']) < 1e-10
+    assert rel_err_rows(pcl, g['cam_prior_lam']) < 1e-10 and rel_err_rows(pll, g['lmk_prior_lam']) < 1e-10
+    assert belief_gap(e.beliefs(), g, '') < 1e-10
+    cm, lm = e.means()
+    assert np.allclose(cm, g['cam_mu'], rtol=1e-9, atol=1e-12) and np.allclose(lm, g['lmk_mu'], rtol=1e-9, atol=1e-12)
+    assert e.are() == pytest.approx(float(g['are0']), rel=1e-9)
+    assert e.energy() == pytest.approx(float(g['energy0']), rel=1e-9)
+    cs, ls = e.covariances()
+    bce, bcl, ble, bll = e.beliefs()
+    assert np.allclose(cs @ bcl, np.eye(6)[None], atol=1e-8) and np.allclose(ls @ bll, np.eye(3)[None], atol=1e-8)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g4_trace_vsmall(eng_mod, oracle_mod, fused):
+    g = golden('G4_trace_vsmall')
+    _, e = make(eng_mod, 'fr1desk_vsmall.txt', fused=fused)
+    assert e.info()['fused'] == fused
+    ares, energies, relin, snaps = replay_with_snaps(oracle_mod, e, 30, (1, 2, 5, 16, 30))
+    assert np.array_equal(relin, g['n_relin'])
+    assert np.allclose(ares, g['are'], rtol=1e-6)
+    assert np.allclose(energies, g['energy'], rtol=1e-5)
+    for k in (1, 2, 5, 16, 30):
+        s = snaps[k]
+        gap = belief_gap(s['bel'], g, f'it{k}_')
+        assert gap < BELIEF_TOL, (k, gap)
+        assert np.allclose(s['mu'][0], g[f'it{k}_cam_mu'], rtol=1e-5, atol=1e-6)
+        assert np.allclose(s['mu'][1], g[f'it{k}_lmk_mu'], rtol=1e-5, atol=1e-6)
+    for k in (1, 16):
+        s = snaps[k]
+        for arr, name in zip(s['msg'], ('msg_cam_eta', 'msg_cam_lam', 'msg_lmk_eta', 'msg_lmk_lam')):
+            err = rel_err_rows(arr, g[f'it{k}_{name}'])
+            assert err < MSG_TOL, (k, name, err)
+        assert np.array_equal(s['st']['iters_since_relin'], g[f'it{k}_iters_since_relin'])
+        assert np.array_equal(s['st']['eta_damping'], g[f'it{k}_eta_damping'])
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g5_gate_small_config2(eng_mod, oracle_mod, fused):
+    """BASELINE config 2 correctness gate: beliefs after 10 and 30 sweeps of fr1desk_small."""
+    g = golden('G5_gate_small')
+    _, e = make(eng_mod, 'fr1desk_small.txt', fused=fused)
+    ares, energies, relin, snaps = replay_with_snaps(oracle_mod, e, 30, (10, 30))
+    assert np.array_equal(relin, g['n_relin'])
+    assert np.allclose(ares, g['are'], rtol=1e-6)
+    g10, g30 = belief_gap(snaps[10]['bel'], g, 'it10_'), belief_gap(snaps[30]['bel'], g, 'it30_')
+    assert g10 < BELIEF_TOL and g30 < BELIEF_TOL, (g10, g30)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g6_fr1desk_config3(eng_mod, oracle_mod, fused):
+    g = golden('G6_fr1desk_5it')
+    _, e = make(eng_mod, 'fr1desk.txt', fused=fused)
+    oracle_mod.replay_ba(e, 5)
+    assert belief_gap(e.beliefs(), g, 'it5_') < BELIEF_TOL
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('loss', ['huber', 'constant'])
+def test_g7_robust_losses(eng_mod, oracle_mod, loss, fused):
+    g = golden('G7_robust_vsmall')
+    _, e = make(eng_mod, 'fr1desk_vsmall.txt', loss=loss, Nstds=3.0, fused=fused)
+    snaps = {}
+
+    def grab(i, graph):
+        if i in (1, 5):
+            snaps[i] = (graph.beliefs(), graph.relin_state())
+    oracle_mod.replay_ba(e, 6, on_iter=grab)
+    assert belief_gap(snaps[1][0], g, f'{loss}_it1_') < BELIEF_TOL
+    assert belief_gap(snaps[5][0], g, f'{loss}_it5_') < BELIEF_TOL
+    st = snaps[5][1]
+    assert np.allclose(st['adaptive_var'], g[f'{loss}_adaptive_var'], rtol=1e-8)
+    assert np.array_equal(st['robust_flag'], g[f'{loss}_robust_flag'])
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g7_float_implementation_prior_weakening(eng_mod, oracle_mod, fused):
+    g = golden('G7_robust_vsmall')
+    _, e = make(eng_mod, 'fr1desk_vsmall.txt', fused=fused)
+    snaps = {}
+
+    def grab(i, graph):
+        if i in (2, 12):
+            snaps[i] = (graph.beliefs(), graph.priors())
+    oracle_mod.replay_ba(e, 13, float_impl=True, on_iter=grab)
+    assert belief_gap(snaps[2][0], g, 'floatimpl_it2_') < BELIEF_TOL
+    assert belief_gap(snaps[12][0], g, 'floatimpl_it12_') < BELIEF_TOL
+    assert np.allclose(snaps[12][1][1][:, 0, 0], g['floatimpl_cam_prior_lambda'], rtol=1e-10)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_g9_synthetic_mini(eng_mod, oracle_mod, fused):
+    g = golden('G9_synthetic_mini')
+    q = BAProblem(K=g['K'], cam_means=g['cam_means'], lmk_means=g['lmk_means'], meas=g['meas'],
+                  cam_idx=g['cam_idx'], lmk_idx=g['lmk_idx'])
+    e = eng_mod.BAEngine.from_problem(q, fused=fused)
+    e.generate_priors_var(50.0)
+    e.update_all_beliefs()
+    snaps = {}
+
+    def grab(i, graph):
+        if i in (1, 5, 20):
+            snaps[i] = graph.beliefs()
+    oracle_mod.replay_ba(e, 21, on_iter=grab)
+    for k in (1, 5, 20):
+        assert belief_gap(snaps[k], g, f'it{k}_') < BELIEF_TOL
+
+
+def oracle_vs_engine(eng_mod, oracle_mod, p, n_sweeps, fused, **kw):
+    o = oracle_mod.OracleBA.from_problem(p, threads=8, **kw)
+    e = eng_mod.BAEngine.from_problem(p, fused=fused, **kw)
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+        oracle_mod.replay_ba(g, n_sweeps)
+    ob, eb = o.beliefs(), e.beliefs()
+    gap = max(rel_err_rows(a, b) for a, b in zip(eb, ob))
+    return gap, o, e
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_oracle_parity_ragged_synthetic(eng_mod, oracle_mod, fused):
+    """Seeded problem with ragged landmark degrees (2..40) and uneven camera degrees, file order shuffled
+    so the camera-major re-ordering of gbp_ba.py:128-130 is exercised."""
+    rng = np.random.default_rng(7)
+    p = make_synthetic(n_cams=24, n_lmks=3000, obs_per_lmk=20, seed=3)
+    keep = np.zeros(p.n_factors, dtype=bool)
+    deg = rng.integers(2, 21, size=p.n_lmks)
+    order = rng.permutation(p.n_factors)
+    seen = np.zeros(p.n_lmks, dtype=np.int64)
+    for i in order:
+        l = p.lmk_idx[i]
+        if seen[l] < deg[l]:
+            keep[i] = True
+            seen[l] += 1
+    sel = rng.permutation(np.nonzero(keep)[0])
+    q = BAProblem(K=p.K, cam_means=p.cam_means, lmk_means=p.lmk_means, meas=p.meas[sel],
+                  cam_idx=p.cam_idx[sel], lmk_idx=p.lmk_idx[sel])
+    gap, o, e = oracle_vs_engine(eng_mod, oracle_mod, q, 20, fused)
+    assert gap < BELIEF_TOL, gap
+    assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
+    assert e.are() == pytest.approx(o.are(), rel=1e-6)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_oracle_parity_flags_and_high_degree(eng_mod, oracle_mod, fused):
+    """robustify=False / local_relin=False sweeps (gbp.py:86-92 flag combinations), plus a landmark seen by
+    270 of 300 cameras (degree > one 256-lane tile)."""
+    p = make_synthetic(n_cams=300, n_lmks=2, obs_per_lmk=270, seed=5)
+    q = make_synthetic(n_cams=300, n_lmks=400, obs_per_lmk=4, seed=6)
+    lm = np.concatenate([p.lmk_means[:2], q.lmk_means])
+    sel = p.lmk_idx < 2
+    prob = BAProblem(K=p.K, cam_means=q.cam_means, lmk_means=lm,
+                     meas=np.concatenate([p.meas[sel], q.meas]),
+                     cam_idx=np.concatenate([p.cam_idx[sel], q.cam_idx]),
+                     lmk_idx=np.concatenate([p.lmk_idx[sel], q.lmk_idx + 2]).astype(np.int32))
+    o = oracle_mod.OracleBA.from_problem(prob, threads=4)
+    e = eng_mod.BAEngine.from_problem(prob, fused=fused)
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+        for k in range(4):
+            g.synchronous_iteration(robustify=False, local_relin=False)
+        for k in range(3):
+            g.synchronous_iteration(robustify=True, local_relin=True)
+        g.synchronous_iteration()                       # the reference's defaults: local_relin=True, robustify=False
+    gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs()))
+    assert gap < BELIEF_TOL, gap
+
+
+def test_fused_and_general_paths_agree(eng_mod, oracle_mod):
+    p = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
+    out = []
+    for fused in (False, True):
+        e = eng_mod.BAEngine.from_problem(p, fused=fused)
+        e.generate_priors_var(50.0)
+        e.update_all_beliefs()
+        oracle_mod.replay_ba(e, 12)
+        out.append(e.beliefs())
+    assert max(rel_err_rows(a, b) for a, b in zip(*out)) < 1e-7
+
+
+def test_set_priors_var_and_per_factor_iters(eng_mod, oracle_mod):
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    rng = np.random.default_rng(0)
+    o = oracle_mod.OracleBA.from_problem(p)
+    e = eng_mod.BAEngine.from_problem(p)
+    covs = []
+    for n, cnt in ((6, p.n_cams), (3, p.n_lmks)):
+        for _ in range(cnt):
+            a = rng.normal(size=(n, n))
+            covs.append(a @ a.T * 1e-3 + np.eye(n) * 1e-2)
+    o.set_priors_var(np.array(covs[:p.n_cams]), np.array(covs[p.n_cams:]))
+    e.set_priors_var(covs)
+    iters = rng.integers(0, 12, size=p.n_factors).astype(np.int32)
+    for g in (o, e):
+        g.update_all_beliefs()
+        g.set_iters_since_relin(iters)
+        g.iterate(6, robustify=True, local_relin=True)
+    assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())) < BELIEF_TOL
+    so, se = o.relin_state(), e.relin_state()
+    assert np.array_equal(so['iters_since_relin'], se['iters_since_relin'])
+    assert np.array_equal(so['eta_damping'], se['eta_damping'])
+
+
+def test_error_paths(eng_mod):
+    from gbp_amd._capi import GbpError
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    bad = p.cam_idx.copy()
+    bad[5] = p.n_cams
+    with pytest.raises(GbpError):
+        eng_mod.BAEngine(p.K, p.cam_means, p.lmk_means, p.meas, bad, p.lmk_idx)
+    e = eng_mod.BAEngine.from_problem(p)
+    with pytest.raises(GbpError):
+        e.messages(f0=p.n_factors - 1, n=5)
+    with pytest.raises(GbpError):
+        e.covariances()                                  # before any belief update: ESTATE
+    empty = eng_mod.BAEngine(p.K, p.cam_means, p.lmk_means, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert empty.F == 0 and empty.residual_sums().tolist() == [0.0, 0.0]
