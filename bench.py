@@ -32,7 +32,7 @@ def algorithmic_bytes(F, L, C):
 def cpu_baseline(problem, budget_s=20.0):
     """Time the CPU oracle (oracle/gbp_oracle.c, a port of the reference's algorithm) on the same workload."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     o = oracle.OracleBA.from_problem(problem, threads=cores)
     o.generate_priors_var(50.0)
     o.update_all_beliefs()
