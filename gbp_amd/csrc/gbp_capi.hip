@@ -175,10 +175,15 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
 static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial)
 {
     if (with_messages && h->fused.enabled) {
-        CHK(time_begin(h));
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->timing) {
+            if (h->ev_used + 2 > h->ev.size())
+                for (int i = 0; i < 2; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev.push_back(e); }
+            e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
+            h->ev_used += 2;
+        }
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, e0, e1);
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
-        CHK(time_end(h));
         return GBP_OK;
     }
     if (with_messages) CHK(launch_factor_stage(h, robustify, local_relin));
