@@ -267,7 +267,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
 
     const size_t Fp = p.Fp, Lp = p.Lp;
     std::vector<double> x0(9 * Fp, 0.0), z(2 * Fp, 0.0);
-    std::vector<int32_t> fcam(Fp, 0), flmk(Fp, 0), state(Fp, 1 << 2);     // iters_since_relin = 1  gbp.py:249
+    std::vector<int32_t> fcam(Fp, 0), flmk(Fp, 0), state(Fp, 1 << STATE_SHIFT);     // iters_since_relin = 1  gbp.py:249
     for (int i = 0; i < F; ++i) {
         const int r = h->int2ref[i], c = h->ref_cam[r], l = h->ref_lmk[r], fi = ref_file[r];
         for (int k = 0; k < 6; ++k) x0[k * Fp + i] = d->cam_means[(size_t)c * 6 + k];     // linpoint = concat(cam.mu, lmk.mu) gbp_ba.py:136
@@ -284,14 +284,14 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
         CHK(upload(h, p.avar, av));
     }
     CHK(upload(h, p.x0, x0)); CHK(upload(h, p.z, z));
-    CHK(upload(h, p.fcam, fcam)); CHK(upload(h, p.flmk, flmk)); CHK(upload(h, p.state, state));
+    CHK(upload(h, p.fcam, fcam)); CHK(upload(h, p.flmk, flmk));
 
     CHK(dev_alloc(h, &p.lbel, 9 * Lp)); CHK(dev_alloc(h, &p.lmu, 3 * Lp)); CHK(dev_alloc(h, &p.lprior, 9 * Lp));
     CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
     {
         std::vector<double> lmu(3 * Lp, 0.0), cb((size_t)std::max(C, 1) * CAMREC, 0.0);
         for (int l = 0; l < L; ++l) for (int k = 0; k < 3; ++k) lmu[k * Lp + l] = d->lmk_means[(size_t)l * 3 + k];   // node.mu = init gbp_ba.py:123
-        for (int c = 0; c < C; ++c) for (int k = 0; k < 6; ++k) cb[(size_t)c * CAMREC + 27 + k] = d->cam_means[(size_t)c * 6 + k];
+        for (int c = 0; c < C; ++c) for (int k = 0; k < 6; ++k) cb[(size_t)c * CAMREC + CAM_MU + k] = d->cam_means[(size_t)c * 6 + k];
         CHK(upload(h, p.lmu, lmu)); CHK(upload(h, p.cbel, cb));
     }
     int *lptr = nullptr, *cptr = nullptr, *cadj = nullptr;
@@ -303,10 +303,11 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(Fp)));
 
     if (!(h->flags & GBP_FLAG_NO_FUSED)) {
-        int rc = fused_plan(h->fused, p, h->h_lptr, fcam, h->stream, prop.multiProcessorCount);
+        int rc = fused_plan(h->fused, p, h->h_lptr, fcam, state, h->stream, prop.multiProcessorCount);
         if (rc < 0) return fail(GBP_EHIP, "building the fused sweep plan failed (%d)", rc);
         if (h->fused.enabled) h->dominant = "k_sweep_fused";
     }
+    CHK(upload(h, p.state, state));                      // after the plan: it embeds the per-tile ranks
     HIPCHK(hipStreamSynchronize(h->stream));
     return GBP_OK;
 }
@@ -390,7 +391,7 @@ int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double
     std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp(9 * (size_t)p.Lp, 0.0);
     for (int c = 0; c < p.C; ++c) {                 // lam_prior = eye * l; eta = lam_prior @ mu  (gbp_ba.py:32-34)
         for (int k = 0; k < 6; ++k) {
-            cp[(size_t)c * 27 + k] = cam_lambda[c] * cb[(size_t)c * CAMREC + 27 + k];
+            cp[(size_t)c * 27 + k] = cam_lambda[c] * cb[(size_t)c * CAMREC + CAM_MU + k];
             cp[(size_t)c * 27 + 6 + Sym<6>::at(k, k)] = cam_lambda[c];
         }
     }
@@ -529,7 +530,7 @@ int gbp_ba_energy(gbp_ba_t *h, double *out)
 static void unpack6(const double *pk, double *dense) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) dense[i * 6 + j] = pk[Sym<6>::at(std::min(i, j), std::max(i, j))]; }
 static void unpack3(const double *pk, double *dense) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dense[i * 3 + j] = pk[Sym<3>::at(std::min(i, j), std::max(i, j))]; }
 
-static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, const double *d_lmk,
+static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_off, const double *d_lmk,
                         double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     const Params &p = h->p;
@@ -537,8 +538,8 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, const do
         std::vector<double> cb;
         CHK(download(h, cb, d_cam, (size_t)std::max(p.C, 1) * cam_stride));
         for (int c = 0; c < p.C; ++c) {
-            if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)c * 6 + k] = cb[(size_t)c * cam_stride + k];
-            if (cam_lam) unpack6(&cb[(size_t)c * cam_stride + 6], cam_lam + (size_t)c * 36);
+            if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)c * 6 + k] = cb[(size_t)c * cam_stride + cam_off + k];
+            if (cam_lam) unpack6(&cb[(size_t)c * cam_stride + cam_off + 6], cam_lam + (size_t)c * 36);
         }
     }
     if (lmk_eta || lmk_lam) {
@@ -559,13 +560,13 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, const do
 int gbp_ba_get_beliefs(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
-    return get_var_info(h, h->p.cbel, CAMREC, h->p.lbel, cam_eta, cam_lam, lmk_eta, lmk_lam);
+    return get_var_info(h, h->p.cbel, CAMREC, CAM_ETA, h->p.lbel, cam_eta, cam_lam, lmk_eta, lmk_lam);
 }
 
 int gbp_ba_get_priors(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
-    return get_var_info(h, h->p.cprior, 27, h->p.lprior, cam_eta, cam_lam, lmk_eta, lmk_lam);
+    return get_var_info(h, h->p.cprior, 27, 0, h->p.lprior, cam_eta, cam_lam, lmk_eta, lmk_lam);
 }
 
 int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
@@ -575,7 +576,7 @@ int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
     if (cam_mu) {
         std::vector<double> cb;
         CHK(download(h, cb, p.cbel, (size_t)std::max(p.C, 1) * CAMREC));
-        for (int c = 0; c < p.C; ++c) for (int k = 0; k < 6; ++k) cam_mu[(size_t)c * 6 + k] = cb[(size_t)c * CAMREC + 27 + k];
+        for (int c = 0; c < p.C; ++c) for (int k = 0; k < 6; ++k) cam_mu[(size_t)c * 6 + k] = cb[(size_t)c * CAMREC + CAM_MU + k];
     }
     if (lmk_mu) {
         std::vector<double> lm;
@@ -680,7 +681,7 @@ int gbp_ba_get_relin_state(gbp_ba_t *h, int32_t *iters, double *eta_damping, dou
     if (adaptive_var && p.loss != GBP_LOSS_NONE) CHK(download(h, av, p.avar, (size_t)p.Fp));
     for (int r = 0; r < p.F; ++r) {
         const int s = st[h->ref2int[r]];
-        if (iters) iters[r] = s >> 2;
+        if (iters) iters[r] = s >> STATE_SHIFT;
         if (eta_damping) eta_damping[r] = (s & 1) ? p.eta_damping : 0.0;
         if (robust_flag) robust_flag[r] = (uint8_t)((s >> 1) & 1);
         if (adaptive_var) adaptive_var[r] = p.loss != GBP_LOSS_NONE ? av[h->ref2int[r]] : p.sigma2;
@@ -697,7 +698,7 @@ int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters)
     CHK(download(h, st, p.state, (size_t)p.Fp));
     for (int r = 0; r < p.F; ++r) {
         int32_t &s = st[h->ref2int[r]];
-        s = (int32_t)(((uint32_t)iters[r] << 2) | ((uint32_t)s & 3u));
+        s = (int32_t)(((uint32_t)iters[r] << STATE_SHIFT) | ((uint32_t)s & ((1u << STATE_SHIFT) - 1u)));
     }
     CHK(upload(h, p.state, st));
     return GBP_OK;

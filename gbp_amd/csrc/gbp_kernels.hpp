@@ -9,11 +9,11 @@
 //       mc[27][Fp]  message to the camera  (eta 6 | Lambda 21 packed)  Factor.messages[0]
 //       ml[9][Fp]   message to the landmark (eta 3 | Lambda 6 packed)  Factor.messages[1]
 //       avar[Fp]    adaptive noise variance (only when loss != none)   gbp.py:242
-//       fcam[Fp]    int32 camera index;  state[Fp] int32 = iters_since_relin<<2 | robust<<1 | damped
+//       fcam[Fp]    int32 camera index;  state[Fp] int32 = iters_since_relin<<12 | rank<<2 | robust<<1 | damped
 //   landmarks, SoA stride Lp:  lbel[9][Lp] (eta 3 | Lambda 6), lmu[3][Lp], lprior[9][Lp];
 //       lptr[L+1] = first internal factor of each landmark (its factors are contiguous)
 //   cameras, array-of-records (gathered per factor, L2 resident: 500 cams = 136 KB):
-//       cbel[C][34] = eta 6 | Lambda 21 | mu 6 | pad;  cprior[C][27]
+//       cbel[C][34] = mu 6 | eta 6 | Lambda 21 | pad;  cprior[C][27] = eta 6 | Lambda 21
 //       cptr[C+1], cadj[F] = internal factor ids of each camera in reference order
 //
 // Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt
@@ -26,7 +26,8 @@
 
 namespace gbp {
 
-constexpr int CAMREC = 34;       // doubles per camera belief record
+constexpr int CAMREC = 34;       // doubles per camera belief record: mu 6 | eta 6 | Lambda 21 | pad
+constexpr int CAM_MU = 0, CAM_ETA = 6, CAM_LAM = 12;
 constexpr int BLOCK = 256;
 
 struct Params {
@@ -46,18 +47,23 @@ struct Params {
     const int *cptr, *cadj;
 };
 
-GBP_DEV int state_iters(int st) { return st >> 2; }
-GBP_DEV int state_pack(int iters, bool robust, bool damped) { return (iters << 2) | (robust ? 2 : 0) | (damped ? 1 : 0); }
+// state word: iters_since_relin << 12 | rank << 2 | robust << 1 | damped.  "rank" (10 bits) is constant per
+// factor: its index among the same-camera factors of its tile (fused sweep); the general kernels carry it along.
+constexpr int STATE_SHIFT = 12;
+constexpr unsigned STATE_RANK_MASK = 0x3ffu;
+GBP_DEV int state_iters(int st) { return st >> STATE_SHIFT; }
+GBP_DEV int state_rank(int st) { return (st >> 2) & (int)STATE_RANK_MASK; }
+GBP_DEV int state_pack(int iters, int rank, bool robust, bool damped)
+{
+    return (int)(((unsigned)iters << STATE_SHIFT) | ((unsigned)rank << 2) | (robust ? 2u : 0u) | (damped ? 1u : 0u));
+}
 
-// The whole per-factor part of FactorGraph.synchronous_iteration (gbp.py:86-92) for one factor:
-// robustify (gbp.py:296-332) -> relinearise test (gbp.py:64-80) -> damping switch (gbp.py:50-51)
-// -> both messages (gbp.py:334-373).  All inputs/outputs are registers; the callers own the
-// memory traffic.
+// Per-factor front half of FactorGraph.synchronous_iteration (gbp.py:86-92): robustify (gbp.py:296-332)
+// -> relinearise test (gbp.py:64-80) -> damping switch (gbp.py:50-51) -> linearisation at the chosen point.
+// Returns true when the factor relinearised (x0 was replaced by the belief means).
 template <int LOSS>
-GBP_DEV void factor_step(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
-                         const double (&etaC)[6], const double (&lamC)[21], const double (&muC)[6],
-                         const double (&etaL)[3], const double (&lamL)[6], const double (&muL)[3],
-                         double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6], bool &relinearised)
+GBP_DEV bool factor_prepare(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
+                            const double (&muC)[6], const double (&muL)[3], Lin &L)
 {
     int iters = state_iters(st);
     bool robust = (st & 2) != 0, damped = (st & 1) != 0;
@@ -70,7 +76,7 @@ GBP_DEV void factor_step(const Params &p, double (&x0)[9], const double (&z)[2],
         avar = p.sigma2;                       // loss None: adaptive = gauss_noise_var  gbp.py:302-303
     }
 
-    relinearised = false;
+    bool relinearised = false;
     if (p.local_relin) {
         double d2 = 0.0;
 #pragma unroll
@@ -90,21 +96,42 @@ GBP_DEV void factor_step(const Params &p, double (&x0)[9], const double (&z)[2],
         }
         if (iters == p.num_undamped) damped = true;      // gbp.py:50-51 (equality, not >=)
     }
-    const double d = p.local_relin ? (damped ? p.eta_damping : 0.0) : p.eta_damping;   // gbp.py:52-54
+    L.d = p.local_relin ? (damped ? p.eta_damping : 0.0) : p.eta_damping;   // gbp.py:52-54
+    L.s = 1.0 / avar;
 
-    double Jc[2][6], Jl[2][3], h[2], rho[2];
-    linearise(x0, p.K, Jc, Jl, h);
+    double h[2];
+    linearise(x0, p.K, L.Jc, L.Jl, h);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc += Jc[r][i] * x0[i];
+        for (int i = 0; i < 6; ++i) acc += L.Jc[r][i] * x0[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc += Jl[r][i] * x0[6 + i];
-        rho[r] = acc + z[r] - h[r];
+        for (int i = 0; i < 3; ++i) acc += L.Jl[r][i] * x0[6 + i];
+        L.rho[r] = acc + z[r] - h[r];
     }
-    factor_messages(Jc, Jl, rho, 1.0 / avar, d, etaC, lamC, etaL, lamL, eC, MC, eL, ML);
-    st = state_pack(iters, robust, damped);
+    st = state_pack(iters, state_rank(st), robust, damped);
+    return relinearised;
+}
+
+// prepare + both messages (Factor.compute_messages gbp.py:334-373: both from the OLD messages, committed together)
+template <int LOSS>
+GBP_DEV void factor_step(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
+                         const double (&etaC)[6], const double (&lamC)[21], const double (&muC)[6],
+                         const double (&etaL)[3], const double (&lamL)[6], const double (&muL)[3],
+                         double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6], bool &relinearised)
+{
+    Lin L;
+    relinearised = factor_prepare<LOSS>(p, x0, z, st, avar, muC, muL, L);
+    double eLn[3], MLn[6], MCn[21];
+    message_to_landmark(L, etaC, lamC, eC, MC, eL, eLn, MLn);
+    message_to_camera(L, etaL, lamL, eL, ML, eC, MCn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eL[i] = eLn[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ML[i] = MLn[i];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) MC[i] = MCn[i];
 }
 
 GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], double (&lam)[21], double (&mu)[6])
@@ -114,11 +141,11 @@ GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], d
 #pragma unroll
     for (int i = 0; i < 17; ++i) { const double2 t = r2[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) eta[i] = v[i];
+    for (int i = 0; i < 6; ++i) mu[i] = v[CAM_MU + i];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) lam[i] = v[6 + i];
+    for (int i = 0; i < 6; ++i) eta[i] = v[CAM_ETA + i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) mu[i] = v[27 + i];
+    for (int i = 0; i < 21; ++i) lam[i] = v[CAM_LAM + i];
 }
 
 // ------------------------------------------------------------------ general sweep, stage 1 --
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(64) void k_cam_finish(Params p, const double *__res
     }
     double *rec = p.cbel + (size_t)c * CAMREC;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) rec[k] = acc[k];
+    for (int k = 0; k < 27; ++k) rec[CAM_ETA + k] = acc[k];
     double eta[6], lam[21], mu[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) eta[k] = acc[k];
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(64) void k_cam_finish(Params p, const double *__res
     for (int k = 0; k < 21; ++k) lam[k] = acc[6 + k];
     spd_solve<6>(lam, eta, mu);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) rec[27 + k] = mu[k];
+    for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
     rec[33] = 0.0;
 }
 
@@ -273,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_residual(Params p, double *__restrict
         const int c = p.fcam[f], l = p.flmk[f];
         double x[9], h[2];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) x[k] = p.cbel[(size_t)c * CAMREC + 27 + k];
+        for (int k = 0; k < 6; ++k) x[k] = p.cbel[(size_t)c * CAMREC + CAM_MU + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) x[6 + k] = p.lmu[k * Lp + l];
         project(x, p.K, h);
@@ -353,7 +380,7 @@ __global__ __launch_bounds__(BLOCK) void k_covariances(Params p, double *__restr
     if (v < p.C) {
         double lam[21], sig[21];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) lam[k] = p.cbel[(size_t)v * CAMREC + 6 + k];
+        for (int k = 0; k < 21; ++k) lam[k] = p.cbel[(size_t)v * CAMREC + CAM_LAM + k];
         spd_inverse<6>(lam, sig);
 #pragma unroll
         for (int k = 0; k < 21; ++k) cam_sig[(size_t)v * 21 + k] = sig[k];
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_scale(double *__restrict__ a, size_t 
 __global__ __launch_bounds__(BLOCK) void k_fill_iters(int *__restrict__ state, int n, int iters)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) state[i] = (iters << 2) | (state[i] & 3);
+    if (i < n) state[i] = (int)(((unsigned)iters << STATE_SHIFT) | ((unsigned)state[i] & ((1u << STATE_SHIFT) - 1u)));
 }
 
 }  // namespace gbp

@@ -210,97 +210,131 @@ GBP_DEV double robust_variance(int loss, double sigma2, double nstds, double r0,
     return m * m;
 }
 
-// One factor's two outgoing messages (Factor.compute_messages gbp.py:334-373, BA-specialised).
-//   in : Jc, Jl, rho, s = 1/adaptive_var, damping d,
-//        camera belief (etaC 6, lamC 21), landmark belief (etaL 3, lamL 6),
-//        old messages: to camera (eC 6, MC 21), to landmark (eL 3, ML 6)
-//   out: eC/MC and eL/ML are overwritten with the new messages (both computed from the OLD ones,
-//        committed together: gbp.py:371-373).
-GBP_DEV void factor_messages(const double (&Jc)[2][6], const double (&Jl)[2][3], const double (&rho)[2],
-                             double s, double d,
-                             const double (&etaC)[6], const double (&lamC)[21],
-                             const double (&etaL)[3], const double (&lamL)[6],
-                             double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6])
+// Linearised factor in the compact form the messages need.
+struct Lin {
+    double Jc[2][6], Jl[2][3], rho[2];   // J = [Jc | Jl], rho = J x0 + z - h(x0)
+    double s, d;                         // 1 / adaptive variance, eta damping
+};
+
+// Message to the LANDMARK: eliminate the camera block (6x6).   Factor.compute_messages, v = 1  gbp.py:340-368
+//   cavity of the camera: cetaC = eta_C - e_C, clamC = Lambda_C - M_C (belief minus this factor's OLD message)
+//   T = s Jc^T Jc + clamC,  u = s Jc^T rho + cetaC
+//   M_L' = Jl^T (sI - s^2 Jc T^-1 Jc^T) Jl,  e_L' = (1-d) s Jl^T (rho - Jc T^-1 u) + d e_L
+// The forward substitutions of Jc^T and u ride along with the LDL^T elimination (augmented columns) and the
+// 2x2 quadratic forms are accumulated pivot by pivot, so nothing but the shrinking trailing block stays live.
+GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], double (&clamC)[21],
+                                        const double (&eLold)[3], double (&eLnew)[3], double (&MLnew)[6])
 {
-    double newMC[21], neweC[6];
-    {   // ---- to the camera: eliminate the landmark (3x3) -------------------------------------
-        double S[6], g[3], invd[3];
+    const double s = L.s;
+    double y0[6], y1[6], u[6];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            g[i] = s * (Jl[0][i] * rho[0] + Jl[1][i] * rho[1]) + (etaL[i] - eL[i]);
+    for (int i = 0; i < 6; ++i) {
+        y0[i] = L.Jc[0][i]; y1[i] = L.Jc[1][i];
+        u[i] = s * (L.Jc[0][i] * L.rho[0] + L.Jc[1][i] * L.rho[1]) + cetaC[i];
 #pragma unroll
-            for (int j = i; j < 3; ++j)
-                S[Sym<3>::at(i, j)] = s * (Jl[0][i] * Jl[0][j] + Jl[1][i] * Jl[1][j]) +
-                                      (lamL[Sym<3>::at(i, j)] - ML[Sym<3>::at(i, j)]);
-        }
-        ldl_factor<3>(S, invd);
-        double y0[3], y1[3];
+        for (int j = i; j < 6; ++j) clamC[Sym<6>::at(i, j)] += s * (L.Jc[0][i] * L.Jc[0][j] + L.Jc[1][i] * L.Jc[1][j]);
+    }
+    double H00 = 0.0, H01 = 0.0, H11 = 0.0, k0 = 0.0, k1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { y0[i] = Jl[0][i]; y1[i] = Jl[1][i]; }
-        ldl_forward<3>(S, y0); ldl_forward<3>(S, y1); ldl_forward<3>(S, g);
-        double G00 = 0.0, G01 = 0.0, G11 = 0.0, k0 = 0.0, k1 = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        const double r = 1.0 / clamC[Sym<6>::at(k, k)];
+        const double t0 = y0[k] * r, t1 = y1[k] * r;
+        H00 += t0 * y0[k]; H01 += t0 * y1[k]; H11 += t1 * y1[k];
+        k0 += t0 * u[k]; k1 += t1 * u[k];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double t0 = y0[i] * invd[i], t1 = y1[i] * invd[i];
-            G00 += t0 * y0[i]; G01 += t0 * y1[i]; G11 += t1 * y1[i];
-            k0 += t0 * g[i]; k1 += t1 * g[i];
-        }
-        const double W00 = s - s * s * G00, W01 = -(s * s) * G01, W11 = s - s * s * G11;
-        const double r0 = s * (rho[0] - k0), r1 = s * (rho[1] - k1);
-        double WJ0[6], WJ1[6];
+        for (int i = k + 1; i < 6; ++i) {
+            const double m = clamC[Sym<6>::at(k, i)] * r;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            WJ0[j] = W00 * Jc[0][j] + W01 * Jc[1][j];
-            WJ1[j] = W01 * Jc[0][j] + W11 * Jc[1][j];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            neweC[i] = (1.0 - d) * (Jc[0][i] * r0 + Jc[1][i] * r1) + d * eC[i];
-#pragma unroll
-            for (int j = i; j < 6; ++j) newMC[Sym<6>::at(i, j)] = Jc[0][i] * WJ0[j] + Jc[1][i] * WJ1[j];
+            for (int j = i; j < 6; ++j) clamC[Sym<6>::at(i, j)] -= m * clamC[Sym<6>::at(k, j)];
+            y0[i] -= m * y0[k]; y1[i] -= m * y1[k]; u[i] -= m * u[k];
         }
     }
-    {   // ---- to the landmark: eliminate the camera (6x6) --------------------------------------
-        double T[21], u[6], invd[6];
+    const double V00 = s - s * s * H00, V01 = -(s * s) * H01, V11 = s - s * s * H11;
+    const double r0 = s * (L.rho[0] - k0), r1 = s * (L.rho[1] - k1);
+    double VJ0[3], VJ1[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            u[i] = s * (Jc[0][i] * rho[0] + Jc[1][i] * rho[1]) + (etaC[i] - eC[i]);
-#pragma unroll
-            for (int j = i; j < 6; ++j)
-                T[Sym<6>::at(i, j)] = s * (Jc[0][i] * Jc[0][j] + Jc[1][i] * Jc[1][j]) +
-                                      (lamC[Sym<6>::at(i, j)] - MC[Sym<6>::at(i, j)]);
-        }
-        ldl_factor<6>(T, invd);
-        double y0[6], y1[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { y0[i] = Jc[0][i]; y1[i] = Jc[1][i]; }
-        ldl_forward<6>(T, y0); ldl_forward<6>(T, y1); ldl_forward<6>(T, u);
-        double H00 = 0.0, H01 = 0.0, H11 = 0.0, k0 = 0.0, k1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double t0 = y0[i] * invd[i], t1 = y1[i] * invd[i];
-            H00 += t0 * y0[i]; H01 += t0 * y1[i]; H11 += t1 * y1[i];
-            k0 += t0 * u[i]; k1 += t1 * u[i];
-        }
-        const double V00 = s - s * s * H00, V01 = -(s * s) * H01, V11 = s - s * s * H11;
-        const double r0 = s * (rho[0] - k0), r1 = s * (rho[1] - k1);
-        double VJ0[3], VJ1[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            VJ0[j] = V00 * Jl[0][j] + V01 * Jl[1][j];
-            VJ1[j] = V01 * Jl[0][j] + V11 * Jl[1][j];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            eL[i] = (1.0 - d) * (Jl[0][i] * r0 + Jl[1][i] * r1) + d * eL[i];
-#pragma unroll
-            for (int j = i; j < 3; ++j) ML[Sym<3>::at(i, j)] = Jl[0][i] * VJ0[j] + Jl[1][i] * VJ1[j];
-        }
+    for (int j = 0; j < 3; ++j) {
+        VJ0[j] = V00 * L.Jl[0][j] + V01 * L.Jl[1][j];
+        VJ1[j] = V01 * L.Jl[0][j] + V11 * L.Jl[1][j];
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) eC[i] = neweC[i];
+    for (int i = 0; i < 3; ++i) {
+        eLnew[i] = (1.0 - L.d) * (L.Jl[0][i] * r0 + L.Jl[1][i] * r1) + L.d * eLold[i];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) MC[i] = newMC[i];
+        for (int j = i; j < 3; ++j) MLnew[Sym<3>::at(i, j)] = L.Jl[0][i] * VJ0[j] + L.Jl[1][i] * VJ1[j];
+    }
+}
+
+// Message to the CAMERA: eliminate the landmark block (3x3).   Factor.compute_messages, v = 0  gbp.py:340-368
+//   cavity of the landmark: cetaL = eta_L - e_L, clamL = Lambda_L - M_L (OLD landmark message)
+//   S = s Jl^T Jl + clamL,  g = s Jl^T rho + cetaL
+//   M_C' = Jc^T (sI - s^2 Jl S^-1 Jl^T) Jc,  e_C' = (1-d) s Jc^T (rho - Jl S^-1 g) + d e_C   (eC in: old, out: new)
+GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], double (&clamL)[6],
+                                      double (&eC)[6], double (&MCnew)[21])
+{
+    const double s = L.s;
+    double y0[3], y1[3], g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        y0[i] = L.Jl[0][i]; y1[i] = L.Jl[1][i];
+        g[i] = s * (L.Jl[0][i] * L.rho[0] + L.Jl[1][i] * L.rho[1]) + cetaL[i];
+#pragma unroll
+        for (int j = i; j < 3; ++j) clamL[Sym<3>::at(i, j)] += s * (L.Jl[0][i] * L.Jl[0][j] + L.Jl[1][i] * L.Jl[1][j]);
+    }
+    double G00 = 0.0, G01 = 0.0, G11 = 0.0, k0 = 0.0, k1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double r = 1.0 / clamL[Sym<3>::at(k, k)];
+        const double t0 = y0[k] * r, t1 = y1[k] * r;
+        G00 += t0 * y0[k]; G01 += t0 * y1[k]; G11 += t1 * y1[k];
+        k0 += t0 * g[k]; k1 += t1 * g[k];
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i) {
+            const double m = clamL[Sym<3>::at(k, i)] * r;
+#pragma unroll
+            for (int j = i; j < 3; ++j) clamL[Sym<3>::at(i, j)] -= m * clamL[Sym<3>::at(k, j)];
+            y0[i] -= m * y0[k]; y1[i] -= m * y1[k]; g[i] -= m * g[k];
+        }
+    }
+    const double W00 = s - s * s * G00, W01 = -(s * s) * G01, W11 = s - s * s * G11;
+    const double r0 = s * (L.rho[0] - k0), r1 = s * (L.rho[1] - k1);
+    double WJ0[6], WJ1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        WJ0[j] = W00 * L.Jc[0][j] + W01 * L.Jc[1][j];
+        WJ1[j] = W01 * L.Jc[0][j] + W11 * L.Jc[1][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        eC[i] = (1.0 - L.d) * (L.Jc[0][i] * r0 + L.Jc[1][i] * r1) + L.d * eC[i];
+#pragma unroll
+        for (int j = i; j < 6; ++j) MCnew[Sym<6>::at(i, j)] = L.Jc[0][i] * WJ0[j] + L.Jc[1][i] * WJ1[j];
+    }
+}
+
+// Belief / old-message interfaces of the two messages (general kernels): form the cavities, then as above.
+GBP_DEV void message_to_landmark(const Lin &L, const double (&etaC)[6], const double (&lamC)[21],
+                                 const double (&eC)[6], const double (&MC)[21], const double (&eLold)[3],
+                                 double (&eLnew)[3], double (&MLnew)[6])
+{
+    double ce[6], cl[21];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ce[i] = etaC[i] - eC[i];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) cl[i] = lamC[i] - MC[i];
+    message_to_landmark_cavity(L, ce, cl, eLold, eLnew, MLnew);
+}
+
+GBP_DEV void message_to_camera(const Lin &L, const double (&etaL)[3], const double (&lamL)[6],
+                               const double (&eLold)[3], const double (&MLold)[6],
+                               double (&eC)[6], double (&MCnew)[21])
+{
+    double ce[3], cl[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ce[i] = etaL[i] - eLold[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cl[i] = lamL[i] - MLold[i];
+    message_to_camera_cavity(L, ce, cl, eC, MCnew);
 }
 
 // max over all 81 signed entries of Lambda_f = s J^T J (np.max(factor.factor.lam), gbp_ba.py:31)

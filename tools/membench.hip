@@ -1,0 +1,102 @@
+// membench.hip -- which HBM access pattern does the sweep's traffic want on MI355X?
+// Streams R "rows" (doubles per factor) in and W rows out for F factors, one lane per factor, with no maths:
+//   soa8    : row-major rows of stride F      (lane i: base + k*F + i),        8 B per lane per access
+//   tile8   : [tile of 64][row][64 lanes]     (one contiguous block per tile), 8 B per lane per access
+//   tile16  : [tile of 64][row pair][64][2]   (one contiguous block per tile), 16 B per lane per access
+//   copy16  : plain float4 copy of the same number of bytes (upper bound)
+// hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o /tmp/membench && /tmp/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+constexpr int R = 47, W = 36;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_stream(const double *__restrict__ in, double *__restrict__ out, int F, int waves_total)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int ntiles = F / 64;
+    for (int t = wave; t < ntiles; t += waves_total) {
+        double v[R];
+        if (MODE == 0) {
+            const size_t f = (size_t)t * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = in[(size_t)k * F + f];
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) s += v[k];
+#pragma unroll
+            for (int k = 0; k < W; ++k) out[(size_t)k * F + f] = v[k] + s;
+        } else if (MODE == 1) {
+            const double *src = in + (size_t)t * R * 64 + lane;
+            double *dst = out + (size_t)t * W * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = src[k * 64];
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) s += v[k];
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k * 64] = v[k] + s;
+        } else {
+            const double2 *src = reinterpret_cast<const double2 *>(in + (size_t)t * (R + 1) * 64) + lane;
+            double2 *dst = reinterpret_cast<double2 *>(out + (size_t)t * W * 64) + lane;
+            double2 u[(R + 1) / 2];
+#pragma unroll
+            for (int k = 0; k < (R + 1) / 2; ++k) u[k] = src[k * 64];
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < (R + 1) / 2; ++k) s += u[k].x + u[k].y;
+#pragma unroll
+            for (int k = 0; k < W / 2; ++k) dst[k * 64] = make_double2(u[k].x + s, u[k].y + s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n_in, size_t n_out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += stride) {
+        const float4 v = in[i];
+        if (i < n_out) out[i] = v; else { acc.x += v.x; acc.y += v.y; }
+    }
+    if (acc.x == 123.456f) out[0] = acc;
+}
+
+template <typename Fn>
+static double time_ms(Fn fn, int reps = 20)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    fn(); fn();
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) fn();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+int main()
+{
+    const int F = 1 << 20;
+    double *in, *out;
+    hipMalloc(&in, sizeof(double) * (size_t)(R + 1) * F);
+    hipMalloc(&out, sizeof(double) * (size_t)W * F);
+    hipMemset(in, 0, sizeof(double) * (size_t)(R + 1) * F);
+    const double bytes = 8.0 * F * (R + W);
+    for (int wpc : {4, 8, 16, 32}) {
+        const int blocks = 256 * wpc / 4, waves = blocks * 4;
+        double a = time_ms([&] { hipLaunchKernelGGL(k_stream<0>, dim3(blocks), dim3(256), 0, 0, in, out, F, waves); });
+        double b = time_ms([&] { hipLaunchKernelGGL(k_stream<1>, dim3(blocks), dim3(256), 0, 0, in, out, F, waves); });
+        double c = time_ms([&] { hipLaunchKernelGGL(k_stream<2>, dim3(blocks), dim3(256), 0, 0, in, out, F, waves); });
+        printf("waves/CU %2d : soa8 %.3f ms %.0f GB/s | tile8 %.3f ms %.0f GB/s | tile16 %.3f ms %.0f GB/s\n", wpc,
+               a, bytes / a / 1e6, b, bytes / b / 1e6, c, (bytes + 8.0 * F) / c / 1e6);
+    }
+    const size_t n_in = (size_t)R * F * 8 / 16, n_out = (size_t)W * F * 8 / 16;
+    double d = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const float4 *)in, (float4 *)out, n_in, n_out); });
+    printf("copy16 (same bytes in/out): %.3f ms %.0f GB/s\n", d, bytes / d / 1e6);
+    return 0;
+}
