@@ -42,7 +42,6 @@ static int fail(int code, const char *fmt, ...)
 
 #define CHK(expr) do { int rc__ = (expr); if (rc__ != GBP_OK) return rc__; } while (0)
 
-static inline int round_up(int n, int m) { return (n + m - 1) / m * m; }
 
 struct gbp_ba {
     Params p{};
@@ -50,9 +49,11 @@ struct gbp_ba {
     int flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // host-side order maps
-    std::vector<int32_t> int2ref, ref2int;       // internal <-> reference factor ids
+    std::vector<int32_t> ref2slot;               // reference factor id -> slot (tile*64 + lane)
     std::vector<int32_t> ref_cam, ref_lmk;       // per reference factor
-    std::vector<int32_t> h_lptr, h_cptr;         // CSR offsets (internal / reference order)
+    std::vector<int32_t> h_cptr;                 // camera CSR offsets in reference order
+    std::vector<int32_t> h_lrow0, h_lrow1;       // per landmark: its slot range [row0, row1)
+    std::vector<int32_t> big_lmks;               // landmarks larger than a tile
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -135,12 +136,13 @@ static int launch_factor_stage(gbp_ba *h, int robustify, int local_relin)
 {
     Params p = h->p;
     p.robustify = robustify; p.local_relin = local_relin;
-    if (!p.F) return GBP_OK;
+    if (!p.T) return GBP_OK;
+    const int nb = grid_for((size_t)p.T * WTILE);
     CHK(time_begin(h));
     switch (p.loss) {
-    case GBP_LOSS_NONE: hipLaunchKernelGGL(k_factor<0>, dim3(grid_for(p.F)), dim3(BLOCK), 0, h->stream, p); break;
-    case GBP_LOSS_HUBER: hipLaunchKernelGGL(k_factor<1>, dim3(grid_for(p.F)), dim3(BLOCK), 0, h->stream, p); break;
-    default: hipLaunchKernelGGL(k_factor<2>, dim3(grid_for(p.F)), dim3(BLOCK), 0, h->stream, p); break;
+    case GBP_LOSS_NONE: hipLaunchKernelGGL(k_factor<0>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+    case GBP_LOSS_HUBER: hipLaunchKernelGGL(k_factor<1>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+    default: hipLaunchKernelGGL(k_factor<2>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
     }
     CHK(time_end(h));
     HIPCHK(hipGetLastError());
@@ -231,8 +233,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     h->flags = d->flags;
 
     Params &p = h->p;
-    p.F = F; p.L = L; p.C = C;
-    p.Fp = round_up(std::max(F, 1), BLOCK); p.Lp = round_up(std::max(L, 1), BLOCK);
+    p.F = F; p.L = L; p.C = C; p.T = 0;
     p.K = Intrinsics{d->K[0], d->K[1], d->K[2], d->K[3]};
     p.sigma2 = d->gauss_noise_std * d->gauss_noise_std;
     p.nstds = d->nstds; p.beta = d->beta; p.eta_damping = d->eta_damping;
@@ -247,6 +248,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
                         i, d->cam_idx[i], d->lmk_idx[i], C, L);
         h->h_cptr[(size_t)d->cam_idx[i] + 1]++;
     }
+    if (C >= (1 << (32 - META_LMK_BITS))) return fail(GBP_EINVAL, "more than %d cameras are not supported", (1 << (32 - META_LMK_BITS)) - 1);
     for (int c = 0; c < C; ++c) h->h_cptr[c + 1] += h->h_cptr[c];
     std::vector<int32_t> ref_file((size_t)F);
     {
@@ -255,59 +257,122 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     }
     h->ref_cam.resize(F); h->ref_lmk.resize(F);
     for (int r = 0; r < F; ++r) { h->ref_cam[r] = d->cam_idx[ref_file[r]]; h->ref_lmk[r] = d->lmk_idx[ref_file[r]]; }
-    // internal order: landmark-major, stable in reference id (= VariableNode.adj_factors order, gbp_ba.py:139)
-    h->h_lptr.assign((size_t)L + 1, 0);
-    for (int r = 0; r < F; ++r) h->h_lptr[(size_t)h->ref_lmk[r] + 1]++;
-    for (int l = 0; l < L; ++l) h->h_lptr[l + 1] += h->h_lptr[l];
-    h->int2ref.resize(F); h->ref2int.resize(F);
+    // landmark-major order, stable in reference id (= VariableNode.adj_factors order, gbp_ba.py:139)
+    std::vector<int32_t> lptr((size_t)L + 1, 0), lm2ref((size_t)F);
+    for (int r = 0; r < F; ++r) lptr[(size_t)h->ref_lmk[r] + 1]++;
+    for (int l = 0; l < L; ++l) lptr[l + 1] += lptr[l];
     {
-        std::vector<int32_t> cur(h->h_lptr.begin(), h->h_lptr.end() - 1);
-        for (int r = 0; r < F; ++r) { int i = cur[h->ref_lmk[r]]++; h->int2ref[i] = r; h->ref2int[r] = i; }
+        std::vector<int32_t> cur(lptr.begin(), lptr.end() - 1);
+        for (int r = 0; r < F; ++r) lm2ref[(size_t)cur[h->ref_lmk[r]]++] = r;
     }
+    // tiles: up to 64 slots / TILE_LMKS whole landmarks each; over-sized landmarks become chunk tiles (nl = 0)
+    std::vector<int4> tiles;
+    h->h_lrow0.assign((size_t)L, 0); h->h_lrow1.assign((size_t)L, 0);
+    h->ref2slot.assign((size_t)F, -1);
+    std::vector<int32_t> slot2ref;
+    {
+        int cur_l0 = 0, cur_nf = 0, cur_nl = 0;
+        auto flush = [&]() {
+            if (cur_nl > 0) { tiles.push_back(make_int4(cur_l0, cur_nl, cur_nf, 0)); slot2ref.resize(tiles.size() * WTILE, -1); }
+            cur_nf = 0; cur_nl = 0;
+        };
+        for (int l = 0; l < L; ++l) {
+            const int deg = lptr[l + 1] - lptr[l];
+            if (deg > WTILE) {
+                flush();
+                h->h_lrow0[l] = (int32_t)(tiles.size() * WTILE);
+                for (int o = 0; o < deg; o += WTILE) {
+                    const int n = std::min(WTILE, deg - o);
+                    const int base = (int)tiles.size() * WTILE;
+                    tiles.push_back(make_int4(l, 0, n, 0));
+                    slot2ref.resize(tiles.size() * WTILE, -1);
+                    for (int j = 0; j < n; ++j) slot2ref[(size_t)base + j] = lm2ref[(size_t)lptr[l] + o + j];
+                }
+                h->h_lrow1[l] = h->h_lrow0[l] + deg;     // chunk tiles are full except the last: the slots are contiguous
+                h->big_lmks.push_back(l);
+                continue;
+            }
+            if (cur_nl > 0 && (cur_nf + deg > WTILE || cur_nl == TILE_LMKS)) flush();
+            if (cur_nl == 0) cur_l0 = l;
+            const int base = (int)tiles.size() * WTILE + cur_nf;
+            slot2ref.resize((tiles.size() + 1) * WTILE, -1);
+            for (int j = 0; j < deg; ++j) slot2ref[(size_t)base + j] = lm2ref[(size_t)lptr[l] + j];
+            h->h_lrow0[l] = base; h->h_lrow1[l] = base + deg;
+            cur_nf += deg; cur_nl += 1;
+        }
+        flush();
+    }
+    const int T = (int)tiles.size();
+    const size_t S = (size_t)T * WTILE;
+    slot2ref.resize(S, -1);
+    p.T = T;
 
-    const size_t Fp = p.Fp, Lp = p.Lp;
-    std::vector<double> x0(9 * Fp, 0.0), z(2 * Fp, 0.0);
-    std::vector<int32_t> fcam(Fp, 0), flmk(Fp, 0), state(Fp, 1 << STATE_SHIFT);     // iters_since_relin = 1  gbp.py:249
-    for (int i = 0; i < F; ++i) {
-        const int r = h->int2ref[i], c = h->ref_cam[r], l = h->ref_lmk[r], fi = ref_file[r];
-        for (int k = 0; k < 6; ++k) x0[k * Fp + i] = d->cam_means[(size_t)c * 6 + k];     // linpoint = concat(cam.mu, lmk.mu) gbp_ba.py:136
-        for (int k = 0; k < 3; ++k) x0[(6 + k) * Fp + i] = d->lmk_means[(size_t)l * 3 + k];
-        z[i] = d->meas[(size_t)fi * 2]; z[Fp + i] = d->meas[(size_t)fi * 2 + 1];
-        fcam[i] = c; flmk[i] = l;
+    std::vector<double> lin(std::max<size_t>(S, 1) * LIN_ROWS, 0.0);
+    std::vector<int32_t> state(std::max<size_t>(S, 1), 1 << STATE_SHIFT);           // iters_since_relin = 1  gbp.py:249
+    std::vector<uint32_t> meta(std::max<size_t>(S, 1), 0u);
+    std::vector<int32_t> stamp((size_t)std::max(C, 1), -1), count((size_t)std::max(C, 1), 0);
+    for (int t = 0; t < T; ++t) {
+        int4 &td = tiles[t];
+        int mr = 0;
+        for (int j = 0; j < td.z; ++j) {
+            const size_t s = (size_t)t * WTILE + j;
+            const int r = slot2ref[s], c = h->ref_cam[r], l = h->ref_lmk[r], fi = ref_file[r];
+            h->ref2slot[r] = (int32_t)s;
+            auto at = [&](int row) { return ((size_t)t * LIN_ROWS + row) * WTILE + j; };
+            for (int k = 0; k < 6; ++k) lin[at(ROW_X0 + k)] = d->cam_means[(size_t)c * 6 + k];     // linpoint = concat(cam.mu, lmk.mu) gbp_ba.py:136
+            for (int k = 0; k < 3; ++k) lin[at(ROW_X0 + 6 + k)] = d->lmk_means[(size_t)l * 3 + k];
+            lin[at(ROW_Z)] = d->meas[(size_t)fi * 2]; lin[at(ROW_Z + 1)] = d->meas[(size_t)fi * 2 + 1];
+            lin[at(ROW_AVAR)] = p.sigma2;                                                       // gbp.py:242
+            // rank among the same-camera factors of the tile (order of the LDS accumulation in the fused sweep)
+            if (stamp[c] != t) { stamp[c] = t; count[c] = 0; }
+            state[s] |= count[c] << 2;
+            mr = std::max(mr, count[c]);
+            count[c]++;
+            meta[s] = ((uint32_t)c << META_LMK_BITS) | (uint32_t)(td.y > 0 ? l - td.x : 0);
+        }
+        td.w = mr;
     }
-    CHK(dev_alloc(h, &p.x0, 9 * Fp)); CHK(dev_alloc(h, &p.z, 2 * Fp));
-    CHK(dev_alloc(h, &p.mc, 27 * Fp)); CHK(dev_alloc(h, &p.ml, 9 * Fp));
-    CHK(dev_alloc(h, &p.fcam, Fp)); CHK(dev_alloc(h, &p.flmk, Fp)); CHK(dev_alloc(h, &p.state, Fp));
-    if (p.loss != GBP_LOSS_NONE) {
-        CHK(dev_alloc(h, &p.avar, Fp));
-        std::vector<double> av(Fp, p.sigma2);                                             // gbp.py:242
-        CHK(upload(h, p.avar, av));
-    }
-    CHK(upload(h, p.x0, x0)); CHK(upload(h, p.z, z));
-    CHK(upload(h, p.fcam, fcam)); CHK(upload(h, p.flmk, flmk));
+    for (int t = 0; t < T; ++t)                       // layout self-check (cheap, set-up only)
+        for (int j = 0; j < tiles[t].z; ++j) {
+            const uint32_t m = meta[(size_t)t * WTILE + j];
+            const int c = (int)(m >> META_LMK_BITS), l = tiles[t].x + (int)(m & ((1u << META_LMK_BITS) - 1u));
+            const int r = slot2ref[(size_t)t * WTILE + j];
+            if (r < 0 || c != h->ref_cam[r] || l != h->ref_lmk[r] || l < 0 || l >= L)
+                return fail(GBP_ESTATE, "internal layout error at tile %d lane %d (cam %d lmk %d ref %d)", t, j, c, l, r);
+        }
+    unsigned *d_meta = nullptr; int4 *d_tiles = nullptr;
+    CHK(dev_alloc(h, &p.lin, std::max<size_t>(S, 1) * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, std::max<size_t>(S, 1) * MSG_ROWS));
+    CHK(dev_alloc(h, &p.state, std::max<size_t>(S, 1))); CHK(dev_alloc(h, &d_meta, std::max<size_t>(S, 1)));
+    CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1)));
+    CHK(upload(h, p.lin, lin)); CHK(upload(h, p.state, state)); CHK(upload(h, d_meta, meta));
+    if (T) CHK(upload(h, d_tiles, tiles));
+    p.meta = d_meta; p.tiles = d_tiles;
 
-    CHK(dev_alloc(h, &p.lbel, 9 * Lp)); CHK(dev_alloc(h, &p.lmu, 3 * Lp)); CHK(dev_alloc(h, &p.lprior, 9 * Lp));
+    CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
     CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
     {
-        std::vector<double> lmu(3 * Lp, 0.0), cb((size_t)std::max(C, 1) * CAMREC, 0.0);
-        for (int l = 0; l < L; ++l) for (int k = 0; k < 3; ++k) lmu[k * Lp + l] = d->lmk_means[(size_t)l * 3 + k];   // node.mu = init gbp_ba.py:123
+        std::vector<double> lr((size_t)std::max(L, 1) * LREC, 0.0), cb((size_t)std::max(C, 1) * CAMREC, 0.0);
+        for (int l = 0; l < L; ++l) {
+            for (int k = 0; k < 3; ++k) lr[(size_t)l * LREC + LR_MU + k] = d->lmk_means[(size_t)l * 3 + k];   // node.mu = init gbp_ba.py:123
+            int32_t rows[2] = {h->h_lrow0[l], h->h_lrow1[l]};
+            memcpy(&lr[(size_t)l * LREC + LR_ROWS], rows, sizeof rows);
+        }
         for (int c = 0; c < C; ++c) for (int k = 0; k < 6; ++k) cb[(size_t)c * CAMREC + CAM_MU + k] = d->cam_means[(size_t)c * 6 + k];
-        CHK(upload(h, p.lmu, lmu)); CHK(upload(h, p.cbel, cb));
+        CHK(upload(h, p.lrec, lr)); CHK(upload(h, p.cbel, cb));
     }
-    int *lptr = nullptr, *cptr = nullptr, *cadj = nullptr;
-    CHK(dev_alloc(h, &lptr, (size_t)L + 1)); CHK(dev_alloc(h, &cptr, (size_t)C + 1)); CHK(dev_alloc(h, &cadj, (size_t)std::max(F, 1)));
-    CHK(upload(h, lptr, h->h_lptr)); CHK(upload(h, cptr, h->h_cptr)); CHK(upload(h, cadj, h->ref2int));
-    p.lptr = lptr; p.cptr = cptr; p.cadj = cadj;
+    int *cptr = nullptr, *cadj = nullptr;
+    CHK(dev_alloc(h, &cptr, (size_t)C + 1)); CHK(dev_alloc(h, &cadj, (size_t)std::max(F, 1)));
+    CHK(upload(h, cptr, h->h_cptr)); CHK(upload(h, cadj, h->ref2slot));
+    p.cptr = cptr; p.cadj = cadj;
 
     CHK(dev_alloc(h, &h->d_partial, (size_t)std::max(C, 1) * 27));
-    CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(Fp)));
+    CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(std::max<size_t>(S, 1))));
 
     if (!(h->flags & GBP_FLAG_NO_FUSED)) {
-        int rc = fused_plan(h->fused, p, h->h_lptr, fcam, state, h->stream, prop.multiProcessorCount);
+        int rc = fused_plan(h->fused, p, h->big_lmks, h->stream, prop.multiProcessorCount);
         if (rc < 0) return fail(GBP_EHIP, "building the fused sweep plan failed (%d)", rc);
         if (h->fused.enabled) h->dominant = "k_sweep_fused";
     }
-    CHK(upload(h, p.state, state));                      // after the plan: it embeds the per-tile ranks
     HIPCHK(hipStreamSynchronize(h->stream));
     return GBP_OK;
 }
@@ -355,28 +420,45 @@ int gbp_ba_sync(gbp_ba_t *h)
 
 // ------------------------------------------------------------------------------- priors ---
 
+static inline size_t n_slots(const gbp_ba *h) { return std::max<size_t>((size_t)h->p.T * WTILE, 1); }
+static inline size_t h_lin_at(size_t slot, int row) { return ((slot >> 6) * LIN_ROWS + row) * WTILE + (slot & 63); }
+static inline size_t h_msg_at(size_t slot, int row) { return ((slot >> 6) * MSG_ROWS + row) * WTILE + (slot & 63); }
+
 int gbp_ba_factor_lambda_max(gbp_ba_t *h, double *cam_max, double *lmk_max)
 {
     ENTER(h);
     const Params &p = h->p;
-    CHK(ensure_tmp(h, sizeof(double) * (size_t)p.Fp));
-    if (p.F) hipLaunchKernelGGL(k_factor_lambda_max, dim3(grid_for(p.F)), dim3(BLOCK), 0, h->stream, p, h->d_tmp);
+    const size_t S = n_slots(h);
+    CHK(ensure_tmp(h, sizeof(double) * S));
+    if (p.T) hipLaunchKernelGGL(k_factor_lambda_max, dim3(grid_for(S)), dim3(BLOCK), 0, h->stream, p, h->d_tmp);
     HIPCHK(hipGetLastError());
     std::vector<double> fm;
-    CHK(download(h, fm, h->d_tmp, (size_t)p.F));
+    CHK(download(h, fm, h->d_tmp, p.T ? S : 0));
     // max_factor_lam = 0.; max over adjacent factors (gbp_ba.py:27-31)
     if (lmk_max)
         for (int l = 0; l < p.L; ++l) {
             double m = 0.0;
-            for (int i = h->h_lptr[l]; i < h->h_lptr[l + 1]; ++i) m = std::max(m, fm[i]);
+            for (int s = h->h_lrow0[l]; s < h->h_lrow1[l]; ++s) m = std::max(m, fm[s]);
             lmk_max[l] = m;
         }
     if (cam_max)
         for (int c = 0; c < p.C; ++c) {
             double m = 0.0;
-            for (int r = h->h_cptr[c]; r < h->h_cptr[c + 1]; ++r) m = std::max(m, fm[h->ref2int[r]]);
+            for (int r = h->h_cptr[c]; r < h->h_cptr[c + 1]; ++r) m = std::max(m, fm[h->ref2slot[r]]);
             cam_max[c] = m;
         }
+    return GBP_OK;
+}
+
+// write landmark priors (packed eta 3 | Lambda 6 per landmark) into the landmark records, keeping the rest
+static int upload_lmk_priors(gbp_ba *h, const std::vector<double> &pri)
+{
+    const Params &p = h->p;
+    std::vector<double> lr;
+    CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
+    for (int l = 0; l < p.L; ++l)
+        for (int k = 0; k < 9; ++k) lr[(size_t)l * LREC + LR_PRIOR + k] = pri[(size_t)l * 9 + k];
+    CHK(upload(h, p.lrec, lr));
     return GBP_OK;
 }
 
@@ -385,10 +467,10 @@ int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double
     ENTER(h);
     const Params &p = h->p;
     if (!cam_lambda || !lmk_lambda) return fail(GBP_EINVAL, "null argument");
-    std::vector<double> cb, lmu;
+    std::vector<double> cb, lr;
     CHK(download(h, cb, p.cbel, (size_t)std::max(p.C, 1) * CAMREC));
-    CHK(download(h, lmu, p.lmu, 3 * (size_t)p.Lp));
-    std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp(9 * (size_t)p.Lp, 0.0);
+    CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
+    std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp((size_t)std::max(p.L, 1) * 9, 0.0);
     for (int c = 0; c < p.C; ++c) {                 // lam_prior = eye * l; eta = lam_prior @ mu  (gbp_ba.py:32-34)
         for (int k = 0; k < 6; ++k) {
             cp[(size_t)c * 27 + k] = cam_lambda[c] * cb[(size_t)c * CAMREC + CAM_MU + k];
@@ -397,12 +479,12 @@ int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double
     }
     for (int l = 0; l < p.L; ++l) {
         for (int k = 0; k < 3; ++k) {
-            lp[(size_t)k * p.Lp + l] = lmk_lambda[l] * lmu[(size_t)k * p.Lp + l];
-            lp[(size_t)(3 + Sym<3>::at(k, k)) * p.Lp + l] = lmk_lambda[l];
+            lp[(size_t)l * 9 + k] = lmk_lambda[l] * lr[(size_t)l * LREC + LR_MU + k];
+            lp[(size_t)l * 9 + 3 + Sym<3>::at(k, k)] = lmk_lambda[l];
         }
     }
-    CHK(upload(h, p.cprior, cp)); CHK(upload(h, p.lprior, lp));
-    return GBP_OK;
+    CHK(upload(h, p.cprior, cp));
+    return upload_lmk_priors(h, lp);
 }
 
 int gbp_ba_generate_priors(gbp_ba_t *h, double weaker_factor)
@@ -422,7 +504,7 @@ int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam,
     ENTER(h);
     const Params &p = h->p;
     if (!cam_eta || !cam_lam || !lmk_eta || !lmk_lam) return fail(GBP_EINVAL, "null argument");
-    std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp(9 * (size_t)p.Lp, 0.0);
+    std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp((size_t)std::max(p.L, 1) * 9, 0.0);
     for (int c = 0; c < p.C; ++c) {
         for (int k = 0; k < 6; ++k) cp[(size_t)c * 27 + k] = cam_eta[(size_t)c * 6 + k];
         for (int i = 0; i < 6; ++i)
@@ -430,22 +512,21 @@ int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam,
                 cp[(size_t)c * 27 + 6 + Sym<6>::at(i, j)] = 0.5 * (cam_lam[(size_t)c * 36 + i * 6 + j] + cam_lam[(size_t)c * 36 + j * 6 + i]);
     }
     for (int l = 0; l < p.L; ++l) {
-        for (int k = 0; k < 3; ++k) lp[(size_t)k * p.Lp + l] = lmk_eta[(size_t)l * 3 + k];
+        for (int k = 0; k < 3; ++k) lp[(size_t)l * 9 + k] = lmk_eta[(size_t)l * 3 + k];
         for (int i = 0; i < 3; ++i)
             for (int j = i; j < 3; ++j)
-                lp[(size_t)(3 + Sym<3>::at(i, j)) * p.Lp + l] = 0.5 * (lmk_lam[(size_t)l * 9 + i * 3 + j] + lmk_lam[(size_t)l * 9 + j * 3 + i]);
+                lp[(size_t)l * 9 + 3 + Sym<3>::at(i, j)] = 0.5 * (lmk_lam[(size_t)l * 9 + i * 3 + j] + lmk_lam[(size_t)l * 9 + j * 3 + i]);
     }
-    CHK(upload(h, p.cprior, cp)); CHK(upload(h, p.lprior, lp));
-    return GBP_OK;
+    CHK(upload(h, p.cprior, cp));
+    return upload_lmk_priors(h, lp);
 }
 
 int gbp_ba_weaken_priors(gbp_ba_t *h, double factor)
 {
     ENTER(h);
     const Params &p = h->p;
-    const size_t nc = (size_t)p.C * 27, nl = 9 * (size_t)p.Lp;
-    if (nc) hipLaunchKernelGGL(k_scale, dim3(grid_for(nc)), dim3(BLOCK), 0, h->stream, p.cprior, nc, factor);
-    if (p.L) hipLaunchKernelGGL(k_scale, dim3(grid_for(nl)), dim3(BLOCK), 0, h->stream, p.lprior, nl, factor);
+    const size_t n = (size_t)p.C * 27 + (size_t)p.L * 9;
+    if (n) hipLaunchKernelGGL(k_weaken_priors, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, factor);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }
@@ -498,7 +579,7 @@ int gbp_ba_residual_sums(gbp_ba_t *h, double out[2])
     const Params &p = h->p;
     out[0] = out[1] = 0.0;
     if (!p.F) return GBP_OK;
-    const int nb = grid_for(p.F);
+    const int nb = grid_for(n_slots(h));
     hipLaunchKernelGGL(k_residual, dim3(nb), dim3(BLOCK), 0, h->stream, p, h->d_red);
     HIPCHK(hipGetLastError());
     std::vector<double> part;
@@ -530,7 +611,8 @@ int gbp_ba_energy(gbp_ba_t *h, double *out)
 static void unpack6(const double *pk, double *dense) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) dense[i * 6 + j] = pk[Sym<6>::at(std::min(i, j), std::max(i, j))]; }
 static void unpack3(const double *pk, double *dense) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dense[i * 3 + j] = pk[Sym<3>::at(std::min(i, j), std::max(i, j))]; }
 
-static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_off, const double *d_lmk,
+// cameras: records of `cam_stride` doubles with (eta 6 | Lambda 21) at cam_off; landmarks: lrec with (eta 3 | Lambda 6) at lmk_off
+static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_off, int lmk_off,
                         double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     const Params &p = h->p;
@@ -543,15 +625,11 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_
         }
     }
     if (lmk_eta || lmk_lam) {
-        std::vector<double> lb;
-        CHK(download(h, lb, d_lmk, 9 * (size_t)p.Lp));
+        std::vector<double> lr;
+        CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
         for (int l = 0; l < p.L; ++l) {
-            if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)l * 3 + k] = lb[(size_t)k * p.Lp + l];
-            if (lmk_lam) {
-                double pk[6];
-                for (int k = 0; k < 6; ++k) pk[k] = lb[(size_t)(3 + k) * p.Lp + l];
-                unpack3(pk, lmk_lam + (size_t)l * 9);
-            }
+            if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)l * 3 + k] = lr[(size_t)l * LREC + lmk_off + k];
+            if (lmk_lam) unpack3(&lr[(size_t)l * LREC + lmk_off + 3], lmk_lam + (size_t)l * 9);
         }
     }
     return GBP_OK;
@@ -560,13 +638,13 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_
 int gbp_ba_get_beliefs(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
-    return get_var_info(h, h->p.cbel, CAMREC, CAM_ETA, h->p.lbel, cam_eta, cam_lam, lmk_eta, lmk_lam);
+    return get_var_info(h, h->p.cbel, CAMREC, CAM_ETA, LR_BEL, cam_eta, cam_lam, lmk_eta, lmk_lam);
 }
 
 int gbp_ba_get_priors(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
-    return get_var_info(h, h->p.cprior, 27, 0, h->p.lprior, cam_eta, cam_lam, lmk_eta, lmk_lam);
+    return get_var_info(h, h->p.cprior, 27, 0, LR_PRIOR, cam_eta, cam_lam, lmk_eta, lmk_lam);
 }
 
 int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
@@ -579,9 +657,9 @@ int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
         for (int c = 0; c < p.C; ++c) for (int k = 0; k < 6; ++k) cam_mu[(size_t)c * 6 + k] = cb[(size_t)c * CAMREC + CAM_MU + k];
     }
     if (lmk_mu) {
-        std::vector<double> lm;
-        CHK(download(h, lm, p.lmu, 3 * (size_t)p.Lp));
-        for (int l = 0; l < p.L; ++l) for (int k = 0; k < 3; ++k) lmk_mu[(size_t)l * 3 + k] = lm[(size_t)k * p.Lp + l];
+        std::vector<double> lr;
+        CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
+        for (int l = 0; l < p.L; ++l) for (int k = 0; k < 3; ++k) lmk_mu[(size_t)l * 3 + k] = lr[(size_t)l * LREC + LR_MU + k];
     }
     return GBP_OK;
 }
@@ -613,24 +691,16 @@ int gbp_ba_get_messages(gbp_ba_t *h, int32_t f0, int32_t n, double *cam_eta, dou
     ENTER(h);
     CHK(check_range(h, f0, n));
     const Params &p = h->p;
-    const size_t Fp = p.Fp;
-    if (cam_eta || cam_lam) {
-        std::vector<double> mc;
-        CHK(download(h, mc, p.mc, 27 * Fp));
-        for (int q = 0; q < n; ++q) {
-            const int i = h->ref2int[f0 + q];
-            if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)q * 6 + k] = mc[k * Fp + i];
-            if (cam_lam) { double pk[21]; for (int k = 0; k < 21; ++k) pk[k] = mc[(6 + k) * Fp + i]; unpack6(pk, cam_lam + (size_t)q * 36); }
-        }
-    }
-    if (lmk_eta || lmk_lam) {
-        std::vector<double> ml;
-        CHK(download(h, ml, p.ml, 9 * Fp));
-        for (int q = 0; q < n; ++q) {
-            const int i = h->ref2int[f0 + q];
-            if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)q * 3 + k] = ml[k * Fp + i];
-            if (lmk_lam) { double pk[6]; for (int k = 0; k < 6; ++k) pk[k] = ml[(3 + k) * Fp + i]; unpack3(pk, lmk_lam + (size_t)q * 9); }
-        }
+    if (!n || !(cam_eta || cam_lam || lmk_eta || lmk_lam)) return GBP_OK;
+    std::vector<double> msg;
+    CHK(download(h, msg, p.msg, n_slots(h) * MSG_ROWS));
+    for (int q = 0; q < n; ++q) {
+        const size_t s = (size_t)h->ref2slot[f0 + q];
+        double pk[21];
+        if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)q * 6 + k] = msg[h_msg_at(s, ROW_EC + k)];
+        if (cam_lam) { for (int k = 0; k < 21; ++k) pk[k] = msg[h_msg_at(s, ROW_MC + k)]; unpack6(pk, cam_lam + (size_t)q * 36); }
+        if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)q * 3 + k] = msg[h_msg_at(s, ROW_EL + k)];
+        if (lmk_lam) { for (int k = 0; k < 6; ++k) pk[k] = msg[h_msg_at(s, ROW_ML + k)]; unpack3(pk, lmk_lam + (size_t)q * 9); }
     }
     return GBP_OK;
 }
@@ -640,18 +710,16 @@ int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *
     ENTER(h);
     CHK(check_range(h, f0, n));
     const Params &p = h->p;
-    const size_t Fp = p.Fp;
     if (cam) for (int q = 0; q < n; ++q) cam[q] = h->ref_cam[f0 + q];
     if (lmk) for (int q = 0; q < n; ++q) lmk[q] = h->ref_lmk[f0 + q];
-    if (linpoint) {
-        std::vector<double> x0;
-        CHK(download(h, x0, p.x0, 9 * Fp));
-        for (int q = 0; q < n; ++q) for (int k = 0; k < 9; ++k) linpoint[(size_t)q * 9 + k] = x0[k * Fp + h->ref2int[f0 + q]];
-    }
-    if (meas) {
-        std::vector<double> z;
-        CHK(download(h, z, p.z, 2 * Fp));
-        for (int q = 0; q < n; ++q) { meas[(size_t)q * 2] = z[h->ref2int[f0 + q]]; meas[(size_t)q * 2 + 1] = z[Fp + h->ref2int[f0 + q]]; }
+    if ((linpoint || meas) && n) {
+        std::vector<double> lin;
+        CHK(download(h, lin, p.lin, n_slots(h) * LIN_ROWS));
+        for (int q = 0; q < n; ++q) {
+            const size_t s = (size_t)h->ref2slot[f0 + q];
+            if (linpoint) for (int k = 0; k < 9; ++k) linpoint[(size_t)q * 9 + k] = lin[h_lin_at(s, ROW_X0 + k)];
+            if (meas) { meas[(size_t)q * 2] = lin[h_lin_at(s, ROW_Z)]; meas[(size_t)q * 2 + 1] = lin[h_lin_at(s, ROW_Z + 1)]; }
+        }
     }
     if ((eta || lam) && n) {
         if ((size_t)n > h->ids_cap) {
@@ -660,7 +728,7 @@ int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_ids), sizeof(int) * (size_t)n));
             h->ids_cap = n;
         }
-        HIPCHK(hipMemcpyAsync(h->d_ids, h->ref2int.data() + f0, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ids, h->ref2slot.data() + f0, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
         CHK(ensure_tmp(h, sizeof(double) * 90 * (size_t)n));
         hipLaunchKernelGGL(k_export_factors, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, h->d_ids, n, h->d_tmp, h->d_tmp + 9 * (size_t)n);
         HIPCHK(hipGetLastError());
@@ -676,15 +744,16 @@ int gbp_ba_get_relin_state(gbp_ba_t *h, int32_t *iters, double *eta_damping, dou
     ENTER(h);
     const Params &p = h->p;
     std::vector<int32_t> st;
-    CHK(download(h, st, p.state, (size_t)p.Fp));
-    std::vector<double> av;
-    if (adaptive_var && p.loss != GBP_LOSS_NONE) CHK(download(h, av, p.avar, (size_t)p.Fp));
+    CHK(download(h, st, p.state, n_slots(h)));
+    std::vector<double> lin;
+    if (adaptive_var && p.loss != GBP_LOSS_NONE) CHK(download(h, lin, p.lin, n_slots(h) * LIN_ROWS));
     for (int r = 0; r < p.F; ++r) {
-        const int s = st[h->ref2int[r]];
+        const size_t slot = (size_t)h->ref2slot[r];
+        const int s = st[slot];
         if (iters) iters[r] = s >> STATE_SHIFT;
         if (eta_damping) eta_damping[r] = (s & 1) ? p.eta_damping : 0.0;
         if (robust_flag) robust_flag[r] = (uint8_t)((s >> 1) & 1);
-        if (adaptive_var) adaptive_var[r] = p.loss != GBP_LOSS_NONE ? av[h->ref2int[r]] : p.sigma2;
+        if (adaptive_var) adaptive_var[r] = p.loss != GBP_LOSS_NONE ? lin[h_lin_at(slot, ROW_AVAR)] : p.sigma2;
     }
     return GBP_OK;
 }
@@ -695,9 +764,9 @@ int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters)
     if (!iters) return fail(GBP_EINVAL, "null argument");
     const Params &p = h->p;
     std::vector<int32_t> st;
-    CHK(download(h, st, p.state, (size_t)p.Fp));
+    CHK(download(h, st, p.state, n_slots(h)));
     for (int r = 0; r < p.F; ++r) {
-        int32_t &s = st[h->ref2int[r]];
+        int32_t &s = st[(size_t)h->ref2slot[r]];
         s = (int32_t)(((uint32_t)iters[r] << STATE_SHIFT) | ((uint32_t)s & ((1u << STATE_SHIFT) - 1u)));
     }
     CHK(upload(h, p.state, st));
@@ -707,7 +776,8 @@ int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters)
 int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
 {
     ENTER(h);
-    if (h->p.F) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(h->p.F)), dim3(BLOCK), 0, h->stream, h->p.state, h->p.F, value);
+    const int n = h->p.T * WTILE;
+    if (n) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p.state, n, value);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }
@@ -744,7 +814,7 @@ int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_b
 {
     if (!h) return fail(GBP_EINVAL, "null handle");
     if (fused_path) *fused_path = h->fused.enabled ? 1 : 0;
-    if (n_tiles) *n_tiles = h->fused.n_tiles;
+    if (n_tiles) *n_tiles = h->p.T;
     if (n_blocks) *n_blocks = h->fused.n_blocks;
     return GBP_OK;
 }

@@ -1,54 +1,71 @@
-// gbp_kernels.hpp -- HIP kernels of the GBP bundle-adjustment sweep for gfx950 (MI355X).
+// gbp_kernels.hpp -- data layout + general-purpose HIP kernels of the GBP bundle-adjustment sweep (gfx950).
 //
-// Data layout in HBM (all fp64 unless noted; "packed" = upper triangle row-major):
-//   factors, INTERNAL order = landmark-major (stable by reference factor id inside a landmark),
-//   structure-of-arrays with stride Fp (F rounded up to 256) so lane i of a wave touches
-//   consecutive 8-byte words:
-//       x0[9][Fp]   linearisation point (t, w, y)            Factor.linpoint        gbp.py:231
-//       z[2][Fp]    measurement                              Factor.measurement     gbp.py:233
-//       mc[27][Fp]  message to the camera  (eta 6 | Lambda 21 packed)  Factor.messages[0]
-//       ml[9][Fp]   message to the landmark (eta 3 | Lambda 6 packed)  Factor.messages[1]
-//       avar[Fp]    adaptive noise variance (only when loss != none)   gbp.py:242
-//       fcam[Fp]    int32 camera index;  state[Fp] int32 = iters_since_relin<<12 | rank<<2 | robust<<1 | damped
-//   landmarks, SoA stride Lp:  lbel[9][Lp] (eta 3 | Lambda 6), lmu[3][Lp], lprior[9][Lp];
-//       lptr[L+1] = first internal factor of each landmark (its factors are contiguous)
-//   cameras, array-of-records (gathered per factor, L2 resident: 500 cams = 136 KB):
-//       cbel[C][34] = mu 6 | eta 6 | Lambda 21 | pad;  cprior[C][27] = eta 6 | Lambda 21
-//       cptr[C+1], cadj[F] = internal factor ids of each camera in reference order
+// Data layout in HBM (fp64 unless noted; "packed" = upper triangle, row-major: 6x6 -> 21, 3x3 -> 6)
+// -------------------------------------------------------------------------------------------------
+// Factors live in TILES of 64 slots (one wavefront).  Factors are ordered landmark-major (stable by
+// reference factor id inside a landmark) and a tile owns up to 24 whole landmarks: all factors of those
+// landmarks, nf <= 64 of the 64 slots used.  A landmark with more than 64 factors is cut into "chunk"
+// tiles (nl = 0) that own no landmark.  Slot id = tile*64 + lane.
 //
-// Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt
-// from x0 and z every sweep (2x9 Jacobian = ~150 flops vs 720 bytes of traffic).
+// Everything a factor streams per sweep is TILE-CONTIGUOUS, row-major inside the tile, 64 lanes per row:
+//     lin[tile][12][64]   rows 0-8 x0 = linearisation point (t, w, y)      Factor.linpoint      gbp.py:231
+//                         rows 9-10 z  = measurement                        Factor.measurement   gbp.py:233
+//                         row  11  adaptive noise variance (loss != none)   gbp.py:242
+//     msg[tile][36][64]   rows 0-5 / 6-26  message to the camera  eta / Lambda packed   Factor.messages[0]
+//                         rows 27-29 / 30-35 message to the landmark eta / Lambda packed Factor.messages[1]
+//     state[slot] int32 = iters_since_relin << 12 | rank << 2 | robust << 1 | damped     gbp.py:245-249
+//     meta[slot] uint32 = camera index << 8 | landmark's position inside its tile
+// so lane i of a wave reads 8 consecutive bytes of a 512-byte row and a tile's whole working set is one
+// 18 KB + 6 KB block.  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
+// stride-F arrays reach 3.9 TB/s at 4 waves/CU, as tile-contiguous blocks 5.4 TB/s.)
+// Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt from x0 and z
+// every sweep (2x9 Jacobian ~ 150 flops versus 720 bytes of traffic).
 //
-// General sweep = k_factor (one lane per factor) -> k_lmk_belief (one lane per landmark over its
-// contiguous messages) -> k_cam_partial (one block per camera, gather) -> k_cam_finish.
+// Landmarks: array of records lrec[L][24] = belief (eta 3 | Lambda 6) | mu 3 | prior (eta 3 | Lambda 6) |
+//            {first slot, end slot} as two int32 | pad.  A tile's landmarks are consecutive records.
+// Cameras:   cbel[C][34] = mu 6 | eta 6 | Lambda 21 | pad (gathered per factor, L2-resident: 500 cams = 136 KB),
+//            cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of each camera's factors (reference order).
+//
+// General sweep (any shape) = k_factor (one lane per slot) -> k_lmk_belief (one lane per landmark) ->
+// k_cam_partial (one workgroup per camera, gather) -> k_cam_finish.  The fused sweep is in gbp_fused.hpp.
 #pragma once
 #include "gbp_math.hpp"
 
 namespace gbp {
 
-constexpr int CAMREC = 34;       // doubles per camera belief record: mu 6 | eta 6 | Lambda 21 | pad
+constexpr int WTILE = 64;         // slots per tile = lanes per wavefront
+constexpr int TILE_LMKS = 24;     // most landmarks a tile owns
+constexpr int LIN_ROWS = 12, MSG_ROWS = 36;
+constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_AVAR = 11;
+constexpr int ROW_EC = 0, ROW_MC = 6, ROW_EL = 27, ROW_ML = 30;
+constexpr int LREC = 24;          // doubles per landmark record
+constexpr int LR_BEL = 0, LR_MU = 9, LR_PRIOR = 12, LR_ROWS = 21;
+constexpr int CAMREC = 34;        // doubles per camera record
 constexpr int CAM_MU = 0, CAM_ETA = 6, CAM_LAM = 12;
+constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (camera in the LOW bits + '& 0xffffff' was
+                                   // miscompiled by hipcc 7.2: the mask vanished in front of a v_mad_u64_u32 address multiply)
 constexpr int BLOCK = 256;
 
 struct Params {
-    int F, Fp, L, Lp, C;
+    int F, T, L, C;               // factors, tiles (slots = 64 T), landmarks, cameras
     Intrinsics K;
     double sigma2, nstds, beta, eta_damping;
     int num_undamped, min_linear, loss;
     int robustify, local_relin;
-    // factors
-    double *x0, *z, *mc, *ml, *avar;
-    int *fcam, *flmk, *state;
-    // landmarks
-    double *lbel, *lmu, *lprior;
-    const int *lptr;
-    // cameras
+    double *lin, *msg;            // tile-blocked factor data
+    int *state;
+    const unsigned *meta;
+    const int4 *tiles;            // {first landmark, landmarks owned, slots used, max rank}
+    double *lrec;
     double *cbel, *cprior;
     const int *cptr, *cadj;
 };
 
+GBP_DEV size_t lin_at(int slot, int row) { return ((size_t)(slot >> 6) * LIN_ROWS + row) * WTILE + (slot & 63); }
+GBP_DEV size_t msg_at(int slot, int row) { return ((size_t)(slot >> 6) * MSG_ROWS + row) * WTILE + (slot & 63); }
+
 // state word: iters_since_relin << 12 | rank << 2 | robust << 1 | damped.  "rank" (10 bits) is constant per
-// factor: its index among the same-camera factors of its tile (fused sweep); the general kernels carry it along.
+// factor: its index among the same-camera factors of its tile (fused sweep); every kernel carries it along.
 constexpr int STATE_SHIFT = 12;
 constexpr unsigned STATE_RANK_MASK = 0x3ffu;
 GBP_DEV int state_iters(int st) { return st >> STATE_SHIFT; }
@@ -114,26 +131,6 @@ GBP_DEV bool factor_prepare(const Params &p, double (&x0)[9], const double (&z)[
     return relinearised;
 }
 
-// prepare + both messages (Factor.compute_messages gbp.py:334-373: both from the OLD messages, committed together)
-template <int LOSS>
-GBP_DEV void factor_step(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
-                         const double (&etaC)[6], const double (&lamC)[21], const double (&muC)[6],
-                         const double (&etaL)[3], const double (&lamL)[6], const double (&muL)[3],
-                         double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6], bool &relinearised)
-{
-    Lin L;
-    relinearised = factor_prepare<LOSS>(p, x0, z, st, avar, muC, muL, L);
-    double eLn[3], MLn[6], MCn[21];
-    message_to_landmark(L, etaC, lamC, eC, MC, eL, eLn, MLn);
-    message_to_camera(L, etaL, lamL, eL, ML, eC, MCn);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) eL[i] = eLn[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ML[i] = MLn[i];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) MC[i] = MCn[i];
-}
-
 GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], double (&lam)[21], double (&mu)[6])
 {
     const double2 *r2 = reinterpret_cast<const double2 *>(rec);
@@ -148,95 +145,122 @@ GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], d
     for (int i = 0; i < 21; ++i) lam[i] = v[CAM_LAM + i];
 }
 
+// slot -> (valid, camera, landmark) through the tile table and the meta word
+GBP_DEV bool slot_info(const Params &p, int slot, int &cam, int &lmk)
+{
+    const int4 td = p.tiles[slot >> 6];
+    if ((slot & 63) >= td.z) return false;
+    const unsigned m = p.meta[slot];
+    cam = (int)(m >> META_LMK_BITS);
+    lmk = td.x + (int)(m & ((1u << META_LMK_BITS) - 1u));
+    return true;
+}
+
 // ------------------------------------------------------------------ general sweep, stage 1 --
+// One lane per slot: the per-factor part of synchronous_iteration; both messages are computed from the OLD
+// messages and committed together (Factor.compute_messages gbp.py:334-373).
 template <int LOSS>
 __global__ __launch_bounds__(BLOCK) void k_factor(Params p)
 {
-    const int f = blockIdx.x * BLOCK + threadIdx.x;
-    if (f >= p.F) return;
-    const size_t Fp = (size_t)p.Fp, Lp = (size_t)p.Lp;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= p.T * WTILE) return;
+    int cam, lmk;
+    if (!slot_info(p, slot, cam, lmk)) return;
     double x0[9], z[2], eC[6], MC[21], eL[3], ML[6];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) x0[k] = p.x0[k * Fp + f];
-    z[0] = p.z[f]; z[1] = p.z[Fp + f];
+    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+    z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) eC[k] = p.mc[k * Fp + f];
+    for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) MC[k] = p.mc[(6 + k) * Fp + f];
+    for (int k = 0; k < 21; ++k) MC[k] = p.msg[msg_at(slot, ROW_MC + k)];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) eL[k] = p.ml[k * Fp + f];
+    for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ML[k] = p.ml[(3 + k) * Fp + f];
-    int st = p.state[f];
-    double avar = (LOSS != 0) ? p.avar[f] : p.sigma2;
-    const int c = p.fcam[f], l = p.flmk[f];
+    for (int k = 0; k < 6; ++k) ML[k] = p.msg[msg_at(slot, ROW_ML + k)];
+    int st = p.state[slot];
+    double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
     double etaC[6], lamC[21], muC[6], etaL[3], lamL[6], muL[3];
-    load_cam_record(p.cbel + (size_t)c * CAMREC, etaC, lamC, muC);
+    load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, lamC, muC);
+    const double *lr = p.lrec + (size_t)lmk * LREC;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) etaL[k] = p.lbel[k * Lp + l];
+    for (int k = 0; k < 3; ++k) etaL[k] = lr[LR_BEL + k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) lamL[k] = p.lbel[(3 + k) * Lp + l];
+    for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) muL[k] = p.lmu[k * Lp + l];
+    for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
 
-    bool relin;
-    factor_step<LOSS>(p, x0, z, st, avar, etaC, lamC, muC, etaL, lamL, muL, eC, MC, eL, ML, relin);
+    Lin L;
+    const bool relin = factor_prepare<LOSS>(p, x0, z, st, avar, muC, muL, L);
+    double eLn[3], MLn[6], MCn[21];
+    message_to_landmark(L, etaC, lamC, eC, MC, eL, eLn, MLn);
+    message_to_camera(L, etaL, lamL, eL, ML, eC, MCn);
 
     if (relin) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) p.x0[k * Fp + f] = x0[k];
+        for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) p.mc[k * Fp + f] = eC[k];
+    for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) p.mc[(6 + k) * Fp + f] = MC[k];
+    for (int k = 0; k < 21; ++k) p.msg[msg_at(slot, ROW_MC + k)] = MCn[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p.ml[k * Fp + f] = eL[k];
+    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_EL + k)] = eLn[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) p.ml[(3 + k) * Fp + f] = ML[k];
-    p.state[f] = st;
-    if (LOSS != 0) p.avar[f] = avar;
+    for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_ML + k)] = MLn[k];
+    p.state[slot] = st;
+    if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
 }
 
 // ------------------------------------------------------------------ general sweep, stage 2 --
-// VariableNode.update_belief for landmarks (gbp.py:176-198): prior + messages in adj_factors
-// order (= ascending reference factor id = internal order inside the landmark), then mu.
-__global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
+// VariableNode.update_belief for one landmark (gbp.py:176-198): prior + messages in adj_factors order
+// (= ascending reference factor id = slot order inside the landmark), then mu = Lambda^-1 eta.
+GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
 {
-    const int l = blockIdx.x * BLOCK + threadIdx.x;
-    if (l >= p.L) return;
-    const size_t Fp = (size_t)p.Fp, Lp = (size_t)p.Lp;
+    double *lr = p.lrec + (size_t)l * LREC;
     double acc[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = p.lprior[k * Lp + l];
-    const int f1 = p.lptr[l + 1];
-    for (int f = p.lptr[l]; f < f1; ++f) {
+    for (int k = 0; k < 9; ++k) acc[k] = lr[LR_PRIOR + k];
+    const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
+    for (int s = rows.x; s < rows.y; ++s) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] += p.ml[k * Fp + f];
+        for (int k = 0; k < 9; ++k) acc[k] += p.msg[msg_at(s, ROW_EL + k)];
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) p.lbel[k * Lp + l] = acc[k];
+    for (int k = 0; k < 9; ++k) lr[LR_BEL + k] = acc[k];
     double eta[3] = {acc[0], acc[1], acc[2]}, lam[6] = {acc[3], acc[4], acc[5], acc[6], acc[7], acc[8]}, mu[3];
     spd_solve<3>(lam, eta, mu);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p.lmu[k * Lp + l] = mu[k];
+    for (int k = 0; k < 3; ++k) lr[LR_MU + k] = mu[k];
 }
 
-// One block per camera: sum of the messages of its factors (gathered through cadj), WITHOUT the
-// prior, into partial[c][27].  Fixed shape reduction -> bitwise reproducible.
+__global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l < p.L) landmark_belief_from_hbm(p, l);
+}
+
+// beliefs of a list of landmarks (the ones larger than a tile, after the fused sweep)
+__global__ __launch_bounds__(64) void k_lmk_belief_list(Params p, const int *__restrict__ list, int n)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) landmark_belief_from_hbm(p, list[i]);
+}
+
+// One workgroup per camera: sum of the messages of its factors (gathered through cadj), WITHOUT the
+// prior, into partial[c][27].  Fixed-shape reduction -> bitwise reproducible.
 __global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restrict__ partial)
 {
     __shared__ double red[BLOCK / 64][27];
     const int c = blockIdx.x;
-    const size_t Fp = (size_t)p.Fp;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
     const int e1 = p.cptr[c + 1];
     for (int e = p.cptr[c] + threadIdx.x; e < e1; e += BLOCK) {
-        const int f = p.cadj[e];
+        const int s = p.cadj[e];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] += p.mc[k * Fp + f];
+        for (int k = 0; k < 27; ++k) acc[k] += p.msg[msg_at(s, ROW_EC + k)];
     }
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -259,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restr
     }
 }
 
-// belief_c = prior_c + sum over ranks (fixed order) of partial_r[c]; mu_c = Lambda^-1 eta.
+// belief_c = prior_c + sum over parts (fixed order) of part_r[c]; mu_c = Lambda^-1 eta.
 __global__ __launch_bounds__(64) void k_cam_finish(Params p, const double *__restrict__ gathered, int n_parts,
                                                    size_t part_stride)
 {
@@ -288,25 +312,24 @@ __global__ __launch_bounds__(64) void k_cam_finish(Params p, const double *__res
 }
 
 // ----------------------------------------------------------------------------- diagnostics --
-// Factor.compute_residual at the current belief means (gbp.py:251-259); per-block partial sums of
+// Factor.compute_residual at the current belief means (gbp.py:251-259); per-workgroup partial sums of
 // ||r|| (BAFactorGraph.are gbp_ba.py:61-69) and 0.5||r||^2/adaptive_var (FactorGraph.energy gbp.py:36-44).
 __global__ __launch_bounds__(BLOCK) void k_residual(Params p, double *__restrict__ partials)
 {
     __shared__ double red[BLOCK / 64][2];
-    const int f = blockIdx.x * BLOCK + threadIdx.x;
-    const size_t Fp = (size_t)p.Fp, Lp = (size_t)p.Lp;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
     double nr = 0.0, en = 0.0;
-    if (f < p.F) {
-        const int c = p.fcam[f], l = p.flmk[f];
+    int cam, lmk;
+    if (slot < p.T * WTILE && slot_info(p, slot, cam, lmk)) {
         double x[9], h[2];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) x[k] = p.cbel[(size_t)c * CAMREC + CAM_MU + k];
+        for (int k = 0; k < 6; ++k) x[k] = p.cbel[(size_t)cam * CAMREC + CAM_MU + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) x[6 + k] = p.lmu[k * Lp + l];
+        for (int k = 0; k < 3; ++k) x[6 + k] = p.lrec[(size_t)lmk * LREC + LR_MU + k];
         project(x, p.K, h);
-        const double r0 = h[0] - p.z[f], r1 = h[1] - p.z[Fp + f];
+        const double r0 = h[0] - p.lin[lin_at(slot, ROW_Z)], r1 = h[1] - p.lin[lin_at(slot, ROW_Z + 1)];
         nr = sqrt(r0 * r0 + r1 * r1);
-        const double av = p.loss != 0 ? p.avar[f] : p.sigma2;
+        const double av = p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
         en = 0.5 * (nr * nr) / av;
     }
 #pragma unroll
@@ -323,31 +346,31 @@ __global__ __launch_bounds__(BLOCK) void k_residual(Params p, double *__restrict
 }
 
 // ---------------------------------------------------------------------------------- set-up --
-// np.max(factor.factor.lam) per factor at its current linearisation point (gbp_ba.py:31)
+// np.max(factor.factor.lam) per factor at its current linearisation point (gbp_ba.py:31); 0 for empty slots
 __global__ __launch_bounds__(BLOCK) void k_factor_lambda_max(Params p, double *__restrict__ fmax_out)
 {
-    const int f = blockIdx.x * BLOCK + threadIdx.x;
-    if (f >= p.F) return;
-    const size_t Fp = (size_t)p.Fp;
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= p.T * WTILE) return;
+    int cam, lmk;
+    if (!slot_info(p, slot, cam, lmk)) { fmax_out[slot] = 0.0; return; }
     double x0[9], Jc[2][6], Jl[2][3], h[2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) x0[k] = p.x0[k * Fp + f];
+    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
     linearise(x0, p.K, Jc, Jl, h);
-    const double av = p.loss != 0 ? p.avar[f] : p.sigma2;
-    fmax_out[f] = factor_lambda_max(Jc, Jl, 1.0 / av);
+    const double av = p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+    fmax_out[slot] = factor_lambda_max(Jc, Jl, 1.0 / av);
 }
 
-// dense (eta_f 9, Lambda_f 81) of a range of factors for the parity views (Factor.factor gbp.py:230,292)
-__global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *__restrict__ ids, int n,
+// dense (eta_f 9, Lambda_f 81) of a list of slots for the parity views (Factor.factor gbp.py:230,292)
+__global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *__restrict__ slots, int n,
                                                           double *__restrict__ eta_out, double *__restrict__ lam_out)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const int f = ids[i];
-    const size_t Fp = (size_t)p.Fp;
+    const int slot = slots[i];
     double x0[9], Jc[2][6], Jl[2][3], h[2], J[2][9], rho[2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) x0[k] = p.x0[k * Fp + f];
+    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
     linearise(x0, p.K, Jc, Jl, h);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *_
 #pragma unroll
         for (int k = 0; k < 3; ++k) J[r][6 + k] = Jl[r][k];
     }
-    const double zz[2] = {p.z[f], p.z[Fp + f]};
+    const double zz[2] = {p.lin[lin_at(slot, ROW_Z)], p.lin[lin_at(slot, ROW_Z + 1)]};
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         double acc = 0.0;
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *_
         for (int k = 0; k < 9; ++k) acc += J[r][k] * x0[k];
         rho[r] = acc + zz[r] - h[r];
     }
-    const double s = 1.0 / (p.loss != 0 ? p.avar[f] : p.sigma2);
+    const double s = 1.0 / (p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         eta_out[(size_t)i * 9 + a] = s * (J[0][a] * rho[0] + J[1][a] * rho[1]);
@@ -388,17 +411,23 @@ __global__ __launch_bounds__(BLOCK) void k_covariances(Params p, double *__restr
         const int l = v - p.C;
         double lam[6], sig[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) lam[k] = p.lbel[(size_t)(3 + k) * p.Lp + l];
+        for (int k = 0; k < 6; ++k) lam[k] = p.lrec[(size_t)l * LREC + LR_BEL + 3 + k];
         spd_inverse<3>(lam, sig);
 #pragma unroll
         for (int k = 0; k < 6; ++k) lmk_sig[(size_t)l * 6 + k] = sig[k];
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scale(double *__restrict__ a, size_t n, double factor)
+// BAFactorGraph.weaken_priors (gbp_ba.py:36-42): prior eta and Lambda of every variable times `factor`
+__global__ __launch_bounds__(BLOCK) void k_weaken_priors(Params p, double factor)
 {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) a[i] *= factor;
+    const size_t nc = (size_t)p.C * 27, nl = (size_t)p.L * 9;
+    if (i < nc) p.cprior[i] *= factor;
+    else if (i < nc + nl) {
+        const size_t j = i - nc;
+        p.lrec[(j / 9) * LREC + LR_PRIOR + (j % 9)] *= factor;
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_fill_iters(int *__restrict__ state, int n, int iters)
