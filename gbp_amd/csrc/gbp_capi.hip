@@ -318,7 +318,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
             const size_t s = (size_t)t * WTILE + j;
             const int r = slot2ref[s], c = h->ref_cam[r], l = h->ref_lmk[r], fi = ref_file[r];
             h->ref2slot[r] = (int32_t)s;
-            auto at = [&](int row) { return ((size_t)t * LIN_ROWS + row) * WTILE + j; };
+            auto at = [&](int row) { return (((size_t)t * (LIN_ROWS / 2) + (row >> 1)) * WTILE + j) * 2 + (row & 1); };
             for (int k = 0; k < 6; ++k) lin[at(ROW_X0 + k)] = d->cam_means[(size_t)c * 6 + k];     // linpoint = concat(cam.mu, lmk.mu) gbp_ba.py:136
             for (int k = 0; k < 3; ++k) lin[at(ROW_X0 + 6 + k)] = d->lmk_means[(size_t)l * 3 + k];
             lin[at(ROW_Z)] = d->meas[(size_t)fi * 2]; lin[at(ROW_Z + 1)] = d->meas[(size_t)fi * 2 + 1];
@@ -421,8 +421,8 @@ int gbp_ba_sync(gbp_ba_t *h)
 // ------------------------------------------------------------------------------- priors ---
 
 static inline size_t n_slots(const gbp_ba *h) { return std::max<size_t>((size_t)h->p.T * WTILE, 1); }
-static inline size_t h_lin_at(size_t slot, int row) { return ((slot >> 6) * LIN_ROWS + row) * WTILE + (slot & 63); }
-static inline size_t h_msg_at(size_t slot, int row) { return ((slot >> 6) * MSG_ROWS + row) * WTILE + (slot & 63); }
+static inline size_t h_lin_at(size_t slot, int row) { return (((slot >> 6) * (LIN_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
+static inline size_t h_msg_at(size_t slot, int row) { return (((slot >> 6) * (MSG_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
 
 int gbp_ba_factor_lambda_max(gbp_ba_t *h, double *cam_max, double *lmk_max)
 {

@@ -84,115 +84,94 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
         const int slot = t * WTILE + lane;
-        double *linb = p.lin + (size_t)t * (LIN_ROWS * WTILE) + lane;
-        double *msgb = p.msg + (size_t)t * (MSG_ROWS * WTILE) + lane;
 
-        // the tile's landmark records (belief | mean | prior | rows), one contiguous run: all lanes fetch it
+        // the tile's landmark records (belief | mean | prior | rows) are one contiguous run: the wave fetches it whole
         const int nrec = max(nl, 1) * LREC;                // chunk tiles stage the over-sized landmark td.x
         const double *lsrc = p.lrec + (size_t)l0 * LREC;
         double stage[WAVE_LDS_DOUBLES / 64];
 #pragma unroll
         for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) stage[j] = (j * 64 + lane < nrec) ? lsrc[j * 64 + lane] : 0.0;
 
-        // first round trip: everything the factor streams except the 21 doubles of the old M_C
+        // everything the factor streams + its camera record: one round trip (the SIMD's second wave covers it);
+        // the cavities (belief minus this factor's old message) are formed at once, which frees 21 + 6 + 6 doubles
         unsigned meta = 0;
         int st = 0;
-        double x0[9], z[2], avar = p.sigma2, eC[6], eLo[3], MLo[6];
+        double x0[9], z[2], avar = p.sigma2, eC[6], eL[3], muC[6];
+        double ceC[6], clC[21], ceL[3], clL[6];
         if (active) {
+            double MC[21], ML[6], etaC[6], lamC[21];
             meta = p.meta[slot];
             st = p.state[slot];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) x0[k] = linb[(ROW_X0 + k) * WTILE];
-            z[0] = linb[ROW_Z * WTILE]; z[1] = linb[(ROW_Z + 1) * WTILE];
-            if (LOSS != 0) avar = linb[ROW_AVAR * WTILE];
+            for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+            z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
+            if (LOSS != 0) avar = p.lin[lin_at(slot, ROW_AVAR)];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) eC[k] = msgb[(ROW_EC + k) * WTILE];
+            for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) eLo[k] = msgb[(ROW_EL + k) * WTILE];
+            for (int k = 0; k < 21; ++k) MC[k] = p.msg[msg_at(slot, ROW_MC + k)];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) MLo[k] = msgb[(ROW_ML + k) * WTILE];
+            for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ML[k] = p.msg[msg_at(slot, ROW_ML + k)];
+            load_cam_record(p.cbel + (size_t)(meta >> META_LMK_BITS) * CAMREC, etaC, lamC, muC);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ceC[k] = etaC[k] - eC[k];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) clC[k] = lamC[k] - MC[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) clL[k] = -ML[k];
         }
         const int cam = (int)(meta >> META_LMK_BITS);
-        const double2 *crec = reinterpret_cast<const double2 *>(p.cbel + (size_t)cam * CAMREC);
-        double muC[6];
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const double2 v = crec[i]; muC[2 * i] = v.x; muC[2 * i + 1] = v.y; }
-        }
+
         // landmark records -> wave scratch -> the lanes of their factors
 #pragma unroll
         for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) wl[j * 64 + lane] = stage[j];
         wave_lds_sync();
-        double etaL[3], lamL[6], muL[3];
+        double muL[3];
         if (active) {
             const double *src = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) etaL[k] = src[LR_BEL + k];
+            for (int k = 0; k < 3; ++k) ceL[k] = src[LR_BEL + k] - eL[k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) lamL[k] = src[LR_BEL + 3 + k];
+            for (int k = 0; k < 6; ++k) clL[k] += src[LR_BEL + 3 + k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) muL[k] = src[LR_MU + k];
         }
-        double prior[9];
-        int row0 = 0, row1 = 0;
-        if (lane < nl) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) prior[k] = wl[lane * LREC + LR_PRIOR + k];
-            const int2 rows = *reinterpret_cast<const int2 *>(wl + lane * LREC + LR_ROWS);
-            row0 = rows.x - t * WTILE; row1 = rows.y - t * WTILE;
-        }
         wave_lds_sync();                                   // scratch is free again
 
-        double MC[21], eLn[3], MLn[6];
+        double MCn[21];
         if (active) {
             Lin L;
             const bool relin = factor_prepare<LOSS>(p, x0, z, st, avar, muC, muL, L);
+            double eLn[3], MLn[6];
+            message_to_landmark_cavity(L, ceC, clC, eL, eLn, MLn);
+            message_to_camera_cavity(L, ceL, clL, eC, MCn);
             if (relin) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) linb[(ROW_X0 + k) * WTILE] = x0[k];
+                for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
             }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) p.msg[msg_at(slot, ROW_MC + k)] = MCn[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { p.msg[msg_at(slot, ROW_EL + k)] = eLn[k]; wl[lane * 9 + k] = eLn[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { p.msg[msg_at(slot, ROW_ML + k)] = MLn[k]; wl[lane * 9 + 3 + k] = MLn[k]; }
             p.state[slot] = st;
-            if (LOSS != 0) linb[ROW_AVAR * WTILE] = avar;
-            // Second (and last) round trip: the camera belief (L2) and the old M_C (HBM).  Their addresses are
-            // chained to the linearisation result (after()), so the compiler cannot hoist these 48 doubles into
-            // the linearisation's live range: with two waves per SIMD a wave has 256 registers, and the other
-            // wave covers the exposed latency.
-            {
-                double etaC[6], lamC[21];
-                const double2 *c2 = after(crec, L.rho[0]);
-                const double *m2 = after(static_cast<const double *>(msgb), L.rho[1]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { const double2 v = c2[3 + i]; etaC[2 * i] = v.x; etaC[2 * i + 1] = v.y; }
-#pragma unroll
-                for (int i = 0; i < 10; ++i) { const double2 v = c2[6 + i]; lamC[2 * i] = v.x; lamC[2 * i + 1] = v.y; }
-                lamC[20] = c2[16].x;
-#pragma unroll
-                for (int k = 0; k < 21; ++k) lamC[k] -= m2[(ROW_MC + k) * WTILE];   // cavity Lambda
-#pragma unroll
-                for (int k = 0; k < 6; ++k) etaC[k] -= eC[k];                      // cavity eta
-                message_to_landmark_cavity(L, etaC, lamC, eLo, eLn, MLn);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { msgb[(ROW_EL + k) * WTILE] = eLn[k]; wl[lane * 9 + k] = eLn[k]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { msgb[(ROW_ML + k) * WTILE] = MLn[k]; wl[lane * 9 + 3 + k] = MLn[k]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) lamL[k] -= MLo[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) etaL[k] -= eLo[k];
-            message_to_camera_cavity(L, etaL, lamL, eC, MC);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) msgb[(ROW_EC + k) * WTILE] = eC[k];
-#pragma unroll
-            for (int k = 0; k < 21; ++k) msgb[(ROW_MC + k) * WTILE] = MC[k];
+            if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
         }
         wave_lds_sync();
 
         // landmark beliefs of the tile: prior + messages in adj_factors order (gbp.py:182-193)
         if (lane < nl && !(a.dbg & 4)) {
+            const double *lr = p.lrec + (size_t)(l0 + lane) * LREC;   // prior + rows again (L2 hit): not worth 20 registers
             double b[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) b[k] = prior[k];
+            for (int k = 0; k < 9; ++k) b[k] = lr[LR_PRIOR + k];
+            const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
+            const int row0 = rows.x - t * WTILE, row1 = rows.y - t * WTILE;
             for (int r = row0; r < row1; ++r) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) b[k] += wl[r * 9 + k];
@@ -215,7 +194,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 #pragma unroll
                 for (int k = 0; k < 6; ++k) unsafeAtomicAdd(dst + k, eC[k]);
 #pragma unroll
-                for (int k = 0; k < 21; ++k) unsafeAtomicAdd(dst + 6 + k, MC[k]);
+                for (int k = 0; k < 21; ++k) unsafeAtomicAdd(dst + 6 + k, MCn[k]);
             }
         }
         wave_lds_sync();

@@ -7,7 +7,8 @@
 // landmarks, nf <= 64 of the 64 slots used.  A landmark with more than 64 factors is cut into "chunk"
 // tiles (nl = 0) that own no landmark.  Slot id = tile*64 + lane.
 //
-// Everything a factor streams per sweep is TILE-CONTIGUOUS, row-major inside the tile, 64 lanes per row:
+// Everything a factor streams per sweep is TILE-CONTIGUOUS; inside a tile rows are stored in pairs,
+// [row/2][64 lanes][2], so a lane owns 16 contiguous bytes per pair (one dwordx4 access):
 //     lin[tile][12][64]   rows 0-8 x0 = linearisation point (t, w, y)      Factor.linpoint      gbp.py:231
 //                         rows 9-10 z  = measurement                        Factor.measurement   gbp.py:233
 //                         row  11  adaptive noise variance (loss != none)   gbp.py:242
@@ -15,7 +16,7 @@
 //                         rows 27-29 / 30-35 message to the landmark eta / Lambda packed Factor.messages[1]
 //     state[slot] int32 = iters_since_relin << 12 | rank << 2 | robust << 1 | damped     gbp.py:245-249
 //     meta[slot] uint32 = camera index << 8 | landmark's position inside its tile
-// so lane i of a wave reads 8 consecutive bytes of a 512-byte row and a tile's whole working set is one
+// so a wave's access is one contiguous 1 KB line per row pair and a tile's whole working set is one
 // 18 KB + 6 KB block.  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
 // stride-F arrays reach 3.9 TB/s at 4 waves/CU, as tile-contiguous blocks 5.4 TB/s.)
 // Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt from x0 and z
@@ -45,6 +46,9 @@ constexpr int CAM_MU = 0, CAM_ETA = 6, CAM_LAM = 12;
 constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (camera in the LOW bits + '& 0xffffff' was
                                    // miscompiled by hipcc 7.2: the mask vanished in front of a v_mad_u64_u32 address multiply)
 constexpr int BLOCK = 256;
+#ifndef GBP_KF_WAVES
+#define GBP_KF_WAVES 1
+#endif
 
 struct Params {
     int F, T, L, C;               // factors, tiles (slots = 64 T), landmarks, cameras
@@ -61,8 +65,11 @@ struct Params {
     const int *cptr, *cadj;
 };
 
-GBP_DEV size_t lin_at(int slot, int row) { return ((size_t)(slot >> 6) * LIN_ROWS + row) * WTILE + (slot & 63); }
-GBP_DEV size_t msg_at(int slot, int row) { return ((size_t)(slot >> 6) * MSG_ROWS + row) * WTILE + (slot & 63); }
+// element (slot, row) of a tile block: rows are stored in PAIRS, [row/2][lane][row%2], so that a lane owns 16 contiguous
+// bytes per pair and the fused sweep moves a tile with half the vector-memory instructions (a wave can have at most
+// 64 of them outstanding; 8-byte rows needed ~130 per tile)
+GBP_DEV size_t lin_at(int slot, int row) { return (((size_t)(slot >> 6) * (LIN_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
+GBP_DEV size_t msg_at(int slot, int row) { return (((size_t)(slot >> 6) * (MSG_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
 
 // state word: iters_since_relin << 12 | rank << 2 | robust << 1 | damped.  "rank" (10 bits) is constant per
 // factor: its index among the same-camera factors of its tile (fused sweep); every kernel carries it along.
@@ -160,7 +167,7 @@ GBP_DEV bool slot_info(const Params &p, int slot, int &cam, int &lmk)
 // One lane per slot: the per-factor part of synchronous_iteration; both messages are computed from the OLD
 // messages and committed together (Factor.compute_messages gbp.py:334-373).
 template <int LOSS>
-__global__ __launch_bounds__(BLOCK) void k_factor(Params p)
+__global__ __launch_bounds__(BLOCK, GBP_KF_WAVES) void k_factor(Params p)
 {
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= p.T * WTILE) return;
