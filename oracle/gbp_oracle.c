@@ -534,6 +534,98 @@ void gbpo_iterate(gbpo_t *g, int n_iters, int robustify, int local_relin)
     }
 }
 
+static void residual_one(const gbpo_t *g, int f, double *r);
+
+/* ---------------------------------------------------------- landmark-sharded sweep pieces -- */
+/* Test doubles of the C ABI's gbp_ba_shard_begin / gbp_ba_shard_end (include/gbp_ba.h): the reference has no
+ * multi-device code; these split update_all_beliefs (gbp/gbp.py:56-58) into "landmarks + this shard's camera
+ * message sums" and "cameras from the gathered sums", so the host-side sharding logic can be tested on CPU. */
+void gbpo_update_lmk_beliefs(gbpo_t *g)
+{
+#pragma omp parallel for schedule(static) num_threads(g->nthreads)
+    for (int l = 0; l < g->L; ++l) update_one(g, 0, l);
+}
+
+/* out[c] = sum over this shard's factors of the message to camera c: eta 6 | Lambda 36 (dense), no prior */
+void gbpo_cam_partial(const gbpo_t *g, double *out)
+{
+    for (int c = 0; c < g->C; ++c) {
+        double *o = out + 42 * (size_t)c;
+        for (int k = 0; k < 42; ++k) o[k] = 0.0;
+        for (int e = g->cam_ptr[c]; e < g->cam_ptr[c + 1]; ++e) {
+            size_t f = (size_t)g->cam_adj[e];
+            for (int k = 0; k < 6; ++k) o[k] += g->m_cam_eta[6 * f + k];
+            for (int k = 0; k < 36; ++k) o[6 + k] += g->m_cam_lam[36 * f + k];
+        }
+    }
+}
+
+/* belief_c = prior_c + sum over shards (rank order) of their partial; mu_c = inv(Lambda) eta */
+void gbpo_cam_finish(gbpo_t *g, const double *gathered, int n_parts)
+{
+    for (int c = 0; c < g->C; ++c) {
+        double eta[6], lam[36], S[36];
+        for (int k = 0; k < 6; ++k) eta[k] = g->cam_prior_eta[6 * (size_t)c + k];
+        for (int k = 0; k < 36; ++k) lam[k] = g->cam_prior_lam[36 * (size_t)c + k];
+        for (int r = 0; r < n_parts; ++r) {
+            const double *src = gathered + ((size_t)r * g->C + c) * 42;
+            for (int k = 0; k < 6; ++k) eta[k] += src[k];
+            for (int k = 0; k < 36; ++k) lam[k] += src[6 + k];
+        }
+        for (int k = 0; k < 6; ++k) g->cam_bel_eta[6 * (size_t)c + k] = eta[k];
+        for (int k = 0; k < 36; ++k) g->cam_bel_lam[36 * (size_t)c + k] = lam[k];
+        inv_n(lam, 6, S);
+        for (int a = 0; a < 6; ++a) {
+            double s = 0.0;
+            for (int b = 0; b < 6; ++b) s += S[a * 6 + b] * eta[b];
+            g->cam_mu[6 * (size_t)c + a] = s;
+        }
+    }
+}
+
+/* per-variable max over adjacent factors of max(Lambda_f): the first half of generate_priors_var (gbp_ba.py:27-31) */
+void gbpo_factor_lambda_max(const gbpo_t *g, double *cam_max, double *lmk_max)
+{
+    for (int v = 0; v < g->C + g->L; ++v) {
+        int is_cam = v < g->C, i = is_cam ? v : v - g->C;
+        const int *ptr = is_cam ? g->cam_ptr : g->lmk_ptr, *adj = is_cam ? g->cam_adj : g->lmk_adj;
+        double mx = 0.0;
+        for (int e = ptr[i]; e < ptr[i + 1]; ++e) {
+            const double *lam = g->f_lam + 81 * (size_t)adj[e];
+            for (int k = 0; k < 81; ++k) if (lam[k] > mx) mx = lam[k];
+        }
+        if (is_cam) cam_max[i] = mx; else lmk_max[i] = mx;
+    }
+}
+
+/* Lambda_prior = lambda I, eta_prior = Lambda_prior mu (gbp_ba.py:32-34) from given per-variable scalars */
+void gbpo_set_prior_scalars(gbpo_t *g, const double *cam_lambda, const double *lmk_lambda)
+{
+    for (int c = 0; c < g->C; ++c)
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) g->cam_prior_lam[36 * (size_t)c + a * 6 + b] = (a == b) ? cam_lambda[c] : 0.0;
+            g->cam_prior_eta[6 * (size_t)c + a] = cam_lambda[c] * g->cam_mu[6 * (size_t)c + a];
+        }
+    for (int l = 0; l < g->L; ++l)
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) g->lmk_prior_lam[9 * (size_t)l + a * 3 + b] = (a == b) ? lmk_lambda[l] : 0.0;
+            g->lmk_prior_eta[3 * (size_t)l + a] = lmk_lambda[l] * g->lmk_mu[3 * (size_t)l + a];
+        }
+}
+
+/* un-normalised diagnostics of one shard: {sum ||r||, sum 0.5 ||r||^2 / var} */
+void gbpo_residual_sums(gbpo_t *g, double *out2)
+{
+    out2[0] = 0.0; out2[1] = 0.0;
+    for (int f = 0; f < g->F; ++f) {
+        double r[2];
+        residual_one(g, f, r);
+        double n = sqrt(r[0] * r[0] + r[1] * r[1]);
+        out2[0] += n;
+        out2[1] += 0.5 * (n * n) / g->adaptive_var[f];
+    }
+}
+
 /* ------------------------------------------------------------------------- diagnostics -- */
 
 /* Factor.compute_residual: gbp/gbp.py:251-259 */

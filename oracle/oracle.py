@@ -60,6 +60,12 @@ def lib():
         L.gbpo_get_relin_state.argtypes = [ct.c_void_p, _ip, _dp, _dp, _bp]
         L.gbpo_set_iters_since_relin.argtypes = [ct.c_void_p, _ip]
         L.gbpo_fill_iters_since_relin.argtypes = [ct.c_void_p, ct.c_int]
+        L.gbpo_update_lmk_beliefs.argtypes = [ct.c_void_p]
+        L.gbpo_cam_partial.argtypes = [ct.c_void_p, _dp]
+        L.gbpo_cam_finish.argtypes = [ct.c_void_p, _dp, ct.c_int]
+        L.gbpo_factor_lambda_max.argtypes = [ct.c_void_p, _dp, _dp]
+        L.gbpo_set_prior_scalars.argtypes = [ct.c_void_p, _dp, _dp]
+        L.gbpo_residual_sums.argtypes = [ct.c_void_p, _dp]
         _lib = L
     return _lib
 
@@ -180,6 +186,45 @@ class OracleBA:
             a = np.ascontiguousarray(v, dtype=np.int32)
             assert a.shape == (self.F,)
             lib().gbpo_set_iters_since_relin(self._h, _i(a))
+
+
+class OracleShard(OracleBA):
+    """CPU stand-in for one rank's BAEngine in the landmark-sharded sweep (tests of gbp_amd.sharded only).
+
+    Same five calls the sharded driver makes on the HIP engine (shard_begin / shard_end / factor_lambda_max /
+    set_prior_scalars / residual_sums); the exchange buffer holds 42 doubles per camera (dense) instead of 27."""
+    PARTIAL_DOUBLES = 42
+
+    def factor_lambda_max(self):
+        cm, lm = np.empty(self.C), np.empty(self.L)
+        lib().gbpo_factor_lambda_max(self._h, _d(cm), _d(lm))
+        return cm, lm
+
+    def set_prior_scalars(self, cam_lambda, lmk_lambda):
+        a = np.ascontiguousarray(cam_lambda, dtype=np.float64)
+        b = np.ascontiguousarray(lmk_lambda, dtype=np.float64)
+        lib().gbpo_set_prior_scalars(self._h, _d(a), _d(b))
+
+    def shard_begin_host(self, with_messages=True, robustify=True, local_relin=True):
+        if with_messages:
+            if robustify:
+                lib().gbpo_robustify(self._h)
+            if local_relin:
+                lib().gbpo_relinearise(self._h)
+            lib().gbpo_compute_messages(self._h, int(local_relin))
+        lib().gbpo_update_lmk_beliefs(self._h)
+        out = np.empty(self.C * 42)
+        lib().gbpo_cam_partial(self._h, _d(out))
+        return out
+
+    def shard_end_host(self, gathered, n_ranks):
+        g = np.ascontiguousarray(gathered, dtype=np.float64)
+        lib().gbpo_cam_finish(self._h, _d(g), int(n_ranks))
+
+    def residual_sums(self):
+        out = np.empty(2)
+        lib().gbpo_residual_sums(self._h, _d(out))
+        return out
 
 
 def replay_ba(graph, n_iters, *, float_impl=False, final_prior_std_weaker_factor=100.0, num_weakening_steps=5,

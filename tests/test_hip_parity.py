@@ -293,3 +293,33 @@ def test_error_paths(eng_mod):
         e.covariances()                                  # before any belief update: ESTATE
     empty = eng_mod.BAEngine(p.K, p.cam_means, p.lmk_means, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(0, np.int32))
     assert empty.F == 0 and empty.residual_sums().tolist() == [0.0, 0.0]
+
+
+def test_sharded_driver_single_rank_nccl(eng_mod, oracle_mod):
+    """gbp_amd.sharded on the real engine with RCCL, world_size 1 (the GPU box has one device): the shard_begin /
+    all_gather / shard_end path must reproduce gbp_ba_iterate exactly."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gbp_amd.sharded import ShardedBA
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        p = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
+        g = ShardedBA(p, device=0)
+        e = eng_mod.BAEngine.from_problem(p)
+        for x in (g, e):
+            x.generate_priors_var(50.0)
+            x.update_all_beliefs()
+            oracle_mod.replay_ba(x, 12)
+        g.sync()
+        ce, cl = g.camera_beliefs()
+        _, le, ll = g.local_landmark_beliefs()
+        ref = e.beliefs()
+        assert np.array_equal(ce, ref[0]) and np.array_equal(cl, ref[1])
+        assert np.array_equal(le, ref[2]) and np.array_equal(ll, ref[3])
+        assert g.are() == pytest.approx(e.are(), rel=1e-12)
+    finally:
+        dist.destroy_process_group()
