@@ -55,8 +55,13 @@ class _HipShard:
         self.engine = BAEngine.from_problem(problem, device=device, fused=fused, **cfg)
         self.partial_doubles = CAM_PARTIAL_DOUBLES
         self.device = torch.device('cuda', device)
-        # kernels and the collective share torch's current stream: no cross-stream events needed
-        self.engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # kernels and the collective are ordered on ONE side stream of torch's (a real handle: the legacy default
+        # stream is the null pointer, which gbp_ba_set_stream reads as "the engine's own stream")
+        self.stream = torch.cuda.Stream(self.device)
+        self.engine.set_stream(self.stream.cuda_stream)
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
 
     def new_buffer(self, n):
         return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
@@ -71,7 +76,7 @@ class _HipShard:
         return self.torch.as_tensor(np.ascontiguousarray(a), device=self.device)
 
     def sync(self):
-        self.engine.sync()
+        self.stream.synchronize()
 
 
 class ShardedBA:
@@ -98,8 +103,10 @@ class ShardedBA:
     # ---- set-up ---------------------------------------------------------------------------
     def generate_priors_var(self, weaker_factor=100.0):
         cam_max, lmk_max = self.engine.factor_lambda_max()
-        t = self.shard.to_tensor(cam_max)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)          # max over ALL factors of a camera (gbp_ba.py:28-31)
+        with self._ctx():
+            t = self.shard.to_tensor(cam_max)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)      # max over ALL factors of a camera (gbp_ba.py:28-31)
+        self.shard.sync()
         w2 = float(weaker_factor) ** 2
         self.engine.set_prior_scalars(t.cpu().numpy() / w2, lmk_max / w2)
 
@@ -107,8 +114,13 @@ class ShardedBA:
         self.engine.weaken_priors(f)
 
     # ---- sweep -----------------------------------------------------------------------------
+    def _ctx(self):
+        import contextlib
+        return self.shard.stream_ctx() if hasattr(self.shard, 'stream_ctx') else contextlib.nullcontext()
+
     def _exchange(self):
-        self.dist.all_gather_into_tensor(self._gathered, self._partial)
+        with self._ctx():
+            self.dist.all_gather_into_tensor(self._gathered, self._partial)
 
     def update_all_beliefs(self):
         self.shard.begin(self._partial, False, False, False)
@@ -131,8 +143,11 @@ class ShardedBA:
 
     # ---- diagnostics -----------------------------------------------------------------------
     def _residual_sums(self):
-        t = self.shard.to_tensor(self.engine.residual_sums())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        sums = self.engine.residual_sums()
+        with self._ctx():
+            t = self.shard.to_tensor(sums)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.shard.sync()
         return t.cpu().numpy()
 
     def are(self):
