@@ -1,0 +1,286 @@
+"""Bundle adjustment with GBP on the MI355X behind the reference's `gbp.gbp_ba` names.
+
+`create_ba_graph(bal_file, configs)` returns a BAFactorGraph whose sweep, belief updates, priors and diagnostics are
+HIP kernels (gbp_amd.engine.BAEngine -> include/gbp_ba.h).  `graph.cam_nodes`, `graph.lmk_nodes` and `graph.factors`
+are lazy sequences of thin views over host mirrors of the device state, so scripts written for joeaortiz/gbp
+(ba.py:68-105, vis/ba_vis.py:35-55,105-115) run unchanged -- including per-factor writes to `iters_since_relin`.
+There is no CPU implementation behind this module: without a gfx950 device create_ba_graph raises.
+"""
+import numpy as np
+
+from gbp_amd.balio import read_bal, reference_factor_order
+from gbp_amd.engine import BAEngine
+from utils.gaussian import NdimGaussian
+
+
+class _Lazy:
+    """Sequence of views created on demand (1M Python objects up front would cost more than the solve)."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._cache = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        v = self._cache.get(i)
+        if v is None:
+            v = self._cache[i] = self._make(i)
+        return v
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+
+class _VariableView:
+    """VariableNode surface (gbp.py:156-198) of one camera or landmark."""
+
+    def __init__(self, graph, kind, index):
+        self._g, self._kind, self._i = graph, kind, index
+        self.variableID = index if kind == 0 else graph._C + index
+        self.dofs = 6 if kind == 0 else 3
+        self.prior_lambda_end = -1
+        self.prior_lambda_logdiff = -1
+        if kind == 0:
+            self.c_id = index
+        else:
+            self.l_id = index
+
+    @property
+    def mu(self):
+        return self._g._means()[self._kind][self._i]
+
+    @property
+    def Sigma(self):
+        return self._g._covs()[self._kind][self._i]
+
+    @property
+    def belief(self):
+        b = self._g._beliefs()
+        return NdimGaussian(self.dofs, b[2 * self._kind][self._i], b[2 * self._kind + 1][self._i])
+
+    @property
+    def prior(self):
+        b = self._g._priors()
+        return NdimGaussian(self.dofs, b[2 * self._kind][self._i], b[2 * self._kind + 1][self._i])
+
+    @property
+    def adj_factors(self):
+        return [self._g.factors[int(f)] for f in self._g._adjacent(self._kind, self._i)]
+
+
+class _FactorView:
+    """Factor surface (gbp.py:201-249) of one reprojection factor (reference factor order)."""
+
+    def __init__(self, graph, f):
+        self._g, self.factorID = graph, f
+        self.args = (graph._K,)                          # vis/ba_vis.py:115 reads K from factors[0].args[0]
+        self.loss = graph._configs.get('loss')
+        self.mahalanobis_threshold = graph._configs.get('Nstds')
+        self.gauss_noise_var = float(graph._configs['gauss_noise_std']) ** 2
+        self.dofs_conditional_vars = 9
+
+    @property
+    def iters_since_relin(self):
+        return int(self._g._relin()['iters_since_relin'][self.factorID])
+
+    @iters_since_relin.setter
+    def iters_since_relin(self, v):
+        self._g._write_iters(self.factorID, int(v))
+
+    @property
+    def eta_damping(self):
+        return float(self._g._relin()['eta_damping'][self.factorID])
+
+    @property
+    def adaptive_gauss_noise_var(self):
+        return float(self._g._relin()['adaptive_var'][self.factorID])
+
+    @property
+    def robust_flag(self):
+        return bool(self._g._relin()['robust_flag'][self.factorID])
+
+    @property
+    def adj_vIDs(self):
+        c, l = self._g._cam_of[self.factorID], self._g._lmk_of[self.factorID]
+        return [int(c), int(self._g._C + l)]
+
+    @property
+    def adj_var_nodes(self):
+        return [self._g.cam_nodes[int(self._g._cam_of[self.factorID])], self._g.lmk_nodes[int(self._g._lmk_of[self.factorID])]]
+
+    @property
+    def adj_beliefs(self):
+        return [n.belief for n in self.adj_var_nodes]
+
+    @property
+    def measurement(self):
+        return self._g._engine.factors(self.factorID, 1, dense=False)['z'][0]
+
+    @property
+    def linpoint(self):
+        return self._g._engine.factors(self.factorID, 1, dense=False)['linpoint'][0]
+
+    @property
+    def factor(self):
+        d = self._g._engine.factors(self.factorID, 1)
+        return NdimGaussian(9, d['eta'][0], d['lam'][0])
+
+    @property
+    def messages(self):
+        ce, cl, le, ll = self._g._engine.messages(self.factorID, 1)
+        return [NdimGaussian(6, ce[0], cl[0]), NdimGaussian(3, le[0], ll[0])]
+
+    def compute_residual(self):
+        from gbp.factors import reprojection
+        x = np.concatenate([n.mu for n in self.adj_var_nodes])
+        return reprojection.meas_fn(x, self._g._K) - self.measurement
+
+    def reprojection_err(self):
+        return float(np.linalg.norm(self.compute_residual()))
+
+
+class BAFactorGraph:
+    """gbp/gbp_ba.py:12-69 + the FactorGraph methods ba.py uses (gbp.py:36-92), on the GPU."""
+
+    def __init__(self, problem, configs, device=0):
+        self._configs = dict(configs)
+        self._engine = BAEngine.from_problem(
+            problem, gauss_noise_std=float(configs['gauss_noise_std']), loss=configs.get('loss'),
+            Nstds=float(configs.get('Nstds', 3.0)), beta=float(configs['beta']),
+            num_undamped_iters=int(configs['num_undamped_iters']), min_linear_iters=int(configs['min_linear_iters']),
+            eta_damping=float(configs['eta_damping']), device=device)
+        self._C, self._L, self._F = problem.n_cams, problem.n_lmks, problem.n_factors
+        self._K = np.array([[problem.K[0], 0.0, problem.K[2]], [0.0, problem.K[1], problem.K[3]], [0.0, 0.0, 1.0]])
+        order = reference_factor_order(problem.cam_idx)
+        self._cam_of, self._lmk_of = problem.cam_idx[order], problem.lmk_idx[order]
+        self.nonlinear_factors = True
+        self.eta_damping = configs['eta_damping']
+        self.beta = configs['beta']
+        self.num_undamped_iters = configs['num_undamped_iters']
+        self.min_linear_iters = configs['min_linear_iters']
+        self.cam_nodes = _Lazy(self._C, lambda i: _VariableView(self, 0, i))
+        self.lmk_nodes = _Lazy(self._L, lambda i: _VariableView(self, 1, i))
+        self.factors = _Lazy(self._F, lambda f: _FactorView(self, f))
+        self.var_nodes = self.cam_nodes + self.lmk_nodes if self._C + self._L <= 100000 else None
+        self.n_var_nodes, self.n_factor_nodes, self.n_edges = self._C + self._L, self._F, 2 * self._F
+        self._cache, self._iters_host, self._iters_dirty = {}, None, False
+        self._adj = None
+
+    # ---- host mirrors ------------------------------------------------------------------------------------------
+    def _invalidate(self):
+        self._cache.clear()
+        self._iters_host = None
+
+    def _cached(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    def _means(self):
+        return self._cached('mu', self._engine.means)
+
+    def _beliefs(self):
+        return self._cached('bel', self._engine.beliefs)
+
+    def _priors(self):
+        return self._cached('pri', self._engine.priors)
+
+    def _covs(self):
+        return self._cached('cov', self._engine.covariances)
+
+    def _relin(self):
+        st = self._cached('relin', self._engine.relin_state)
+        if self._iters_host is not None:
+            st = dict(st, iters_since_relin=self._iters_host)
+        return st
+
+    def _write_iters(self, f, v):
+        if self._iters_host is None:
+            self._iters_host = self._engine.relin_state()['iters_since_relin'].copy()
+        self._iters_host[f] = v
+        self._iters_dirty = True
+
+    def _flush(self):
+        if self._iters_dirty:
+            it = self._iters_host
+            if np.all(it == it[0]):
+                self._engine.set_iters_since_relin(int(it[0]))      # ba.py:91-93 writes the same value everywhere
+            else:
+                self._engine.set_iters_since_relin(it)
+            self._iters_dirty = False
+
+    def _adjacent(self, kind, i):
+        if self._adj is None:
+            self._adj = (np.argsort(self._cam_of, kind='stable'), np.searchsorted(np.sort(self._cam_of), np.arange(self._C + 1)),
+                         np.argsort(self._lmk_of, kind='stable'), np.searchsorted(np.sort(self._lmk_of), np.arange(self._L + 1)))
+        order, ptr = (self._adj[0], self._adj[1]) if kind == 0 else (self._adj[2], self._adj[3])
+        return order[ptr[i]:ptr[i + 1]]
+
+    # ---- priors (gbp_ba.py:20-52) ------------------------------------------------------------------------------
+    def generate_priors_var(self, weaker_factor=100):
+        self._flush()
+        self._engine.generate_priors_var(weaker_factor)
+        self._invalidate()
+
+    def weaken_priors(self, weakening_factor):
+        self._engine.weaken_priors(weakening_factor)
+        self._invalidate()
+
+    def set_priors_var(self, priors):
+        self._engine.set_priors_var(priors)
+        self._invalidate()
+
+    # ---- sweep (gbp.py:46-92) ----------------------------------------------------------------------------------
+    def update_all_beliefs(self):
+        self._flush()
+        self._engine.update_all_beliefs()
+        self._invalidate()
+
+    def synchronous_iteration(self, local_relin=True, robustify=False):
+        self._flush()
+        self._engine.synchronous_iteration(local_relin=local_relin, robustify=robustify)
+        self._invalidate()
+
+    def iterate(self, n, robustify=True, local_relin=True):
+        """n sweeps in one call (no reference counterpart: saves the per-call host overhead)."""
+        self._flush()
+        self._engine.iterate(n, robustify=robustify, local_relin=local_relin)
+        self._invalidate()
+
+    # ---- diagnostics (gbp_ba.py:54-69, gbp.py:36-44) -----------------------------------------------------------
+    def are(self):
+        return self._engine.are()
+
+    def energy(self):
+        return self._engine.energy()
+
+    def compute_residuals(self):
+        out = []
+        for f in self.factors:
+            out += list(f.compute_residual())
+        return out
+
+    def get_means(self):
+        cm, lm = self._means()
+        return np.concatenate([cm.reshape(-1), lm.reshape(-1)])
+
+
+# the reference's class names, kept importable
+ReprojectionFactor = _FactorView
+FrameVariableNode = _VariableView
+LandmarkVariableNode = _VariableView
+
+
+def create_ba_graph(bal_file, configs, device=0):
+    """gbp/gbp_ba.py:97-150: read the BAL-style file and build the graph (factors camera-major, linearised at the file means)."""
+    return BAFactorGraph(read_bal(bal_file), configs, device=device)

@@ -1,0 +1,64 @@
+"""Drop-in `gbp.gbp_ba` / `vis` packages on the GPU: the exact call sequence of the reference's ba.py:68-105 (including
+its Python loops over graph.factors and the viewer calls) must print the reference's ARE / energy trace (fixture G5)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import DATA, REPO, belief_gap, golden
+
+pytestmark = pytest.mark.gpu
+COMPAT = os.path.join(REPO, 'gbp_amd', 'compat')
+
+
+@pytest.fixture
+def compat_path():
+    saved = {k: v for k, v in sys.modules.items() if k.split('.')[0] in ('gbp', 'utils', 'vis')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, COMPAT)
+    yield
+    sys.path.remove(COMPAT)
+    for k in list(sys.modules):
+        if k.split('.')[0] in ('gbp', 'utils', 'vis'):
+            del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def test_ba_script_sequence(compat_path):
+    from gbp import gbp_ba
+    import vis
+    g5 = golden('G5_gate_small')
+    configs = dict(gauss_noise_std=2, loss=None, Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8,
+                   eta_damping=0.4, prior_std_weaker_factor=50.0)
+    graph = gbp_ba.create_ba_graph(os.path.join(DATA, 'fr1desk_small.txt'), configs)
+    assert (len(graph.cam_nodes), len(graph.lmk_nodes), len(graph.factors)) == (20, 1216, 3917)
+    graph.generate_priors_var(weaker_factor=50.0)
+    graph.update_all_beliefs()
+    scene = vis.ba_vis.create_scene(graph)
+    viewer = vis.ba_vis.TrimeshSceneViewer(scene=scene, resolution=scene.camera.resolution)
+    viewer.show()
+    ares, energies, relins = [], [], []
+    for i in range(30):
+        if i == 3 or i == 8:
+            for factor in graph.factors:
+                factor.iters_since_relin = 1
+        ares.append(graph.are())
+        energies.append(graph.energy())
+        relins.append(sum(1 for factor in graph.factors if factor.iters_since_relin == 0))
+        viewer.update(graph)
+        graph.synchronous_iteration(robustify=True, local_relin=True)
+    assert relins == list(g5['n_relin'])
+    assert np.allclose(ares, g5['are'], rtol=1e-6) and np.allclose(energies, g5['energy'], rtol=1e-5)
+    bel = (np.array([n.belief.eta for n in graph.cam_nodes]), np.array([n.belief.lam for n in graph.cam_nodes]),
+           np.array([n.belief.eta for n in graph.lmk_nodes]), np.array([n.belief.lam for n in graph.lmk_nodes]))
+    assert belief_gap(bel, g5, 'it30_') < 1e-6
+    # node / factor views
+    f0 = graph.factors[0]
+    assert f0.args[0].shape == (3, 3) and f0.adj_vIDs == [0, 20 + int(graph._lmk_of[0])]
+    assert f0.messages[0].lam.shape == (6, 6) and f0.factor.lam.shape == (9, 9)
+    assert np.allclose(graph.cam_nodes[0].Sigma @ graph.cam_nodes[0].belief.lam, np.eye(6), atol=1e-8)
+    assert len(graph.cam_nodes[3].adj_factors) == int((graph._cam_of == 3).sum())
+    assert viewer.n_updates == 30 and len(viewer.landmarks) == 1216
+    assert abs(f0.reprojection_err() - np.linalg.norm(f0.compute_residual())) < 1e-12
