@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgbp_hip.so')
+LIB_PATH = os.environ.get('GBP_HIP_LIB', os.path.join(_HERE, 'libgbp_hip.so'))   # override: A/B builds of the same ABI
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)

@@ -123,6 +123,30 @@ struct Rot {
     double c1, cI, cW;   // (R^T - I) w^ + w w^T  ==  theta^2 * (c1 w w^T + cI I - cW w^)
 };
 
+// sin and cos of a non-negative angle with a small register footprint (the generic ocml sincos carries a
+// Payne-Hanek path whose registers count against every lane even though axis-angle norms are O(1)):
+// Cody-Waite reduction by pi/2 in three parts (exact products through fma; full accuracy for theta < ~1e9, degrading
+// gracefully beyond), then the classic minimax kernels on [-pi/4, pi/4] (max error < 1 ulp).
+GBP_DEV void sincos_theta(double x, double &sn, double &cs)
+{
+    const double n = rint(x * 6.36619772367581382433e-01);           // 2/pi
+    double r = fma(n, -1.5707963267948966e+00, x);
+    r = fma(n, -6.123233995736766e-17, r);
+    r = fma(n, 1.4973849048591698e-33, r);
+    const double z = r * r;
+    // sin(r) = r + r^3 (S1 + z (S2 + ...)),  cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double s0 = fma(r * z, ps, r);
+    const double c0 = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 GBP_DEV Rot rodrigues(double w0, double w1, double w2)
 {
     Rot o;
@@ -136,7 +160,11 @@ GBP_DEV Rot rodrigues(double w0, double w1, double w2)
         return o;
     }
     double sn, cs;
+#ifdef GBP_OCML_SINCOS
     sincos(th, &sn, &cs);
+#else
+    sincos_theta(th, sn, cs);
+#endif
     const double ith2 = 1.0 / th2;
     const double a = sn / th;
     const double b = (1.0 - cs) * ith2;
