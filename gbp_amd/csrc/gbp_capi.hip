@@ -692,15 +692,24 @@ int gbp_ba_get_messages(gbp_ba_t *h, int32_t f0, int32_t n, double *cam_eta, dou
     CHK(check_range(h, f0, n));
     const Params &p = h->p;
     if (!n || !(cam_eta || cam_lam || lmk_eta || lmk_lam)) return GBP_OK;
-    std::vector<double> msg;
-    CHK(download(h, msg, p.msg, n_slots(h) * MSG_ROWS));
+    if ((size_t)n > h->ids_cap) {
+        if (h->d_ids) HIPCHK(hipFree(h->d_ids));
+        h->d_ids = nullptr; h->ids_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_ids), sizeof(int) * (size_t)n));
+        h->ids_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_ids, h->ref2slot.data() + f0, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    CHK(ensure_tmp(h, sizeof(double) * 36 * (size_t)n));
+    hipLaunchKernelGGL(k_export_messages, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, h->d_ids, n, h->d_tmp);
+    HIPCHK(hipGetLastError());
+    std::vector<double> m;
+    CHK(download(h, m, h->d_tmp, 36 * (size_t)n));
     for (int q = 0; q < n; ++q) {
-        const size_t s = (size_t)h->ref2slot[f0 + q];
-        double pk[21];
-        if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)q * 6 + k] = msg[h_msg_at(s, ROW_EC + k)];
-        if (cam_lam) { for (int k = 0; k < 21; ++k) pk[k] = msg[h_msg_at(s, ROW_MC + k)]; unpack6(pk, cam_lam + (size_t)q * 36); }
-        if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)q * 3 + k] = msg[h_msg_at(s, ROW_EL + k)];
-        if (lmk_lam) { for (int k = 0; k < 6; ++k) pk[k] = msg[h_msg_at(s, ROW_ML + k)]; unpack3(pk, lmk_lam + (size_t)q * 9); }
+        const double *o = &m[(size_t)q * 36];
+        if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)q * 6 + k] = o[k];
+        if (cam_lam) unpack6(o + 6, cam_lam + (size_t)q * 36);
+        if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)q * 3 + k] = o[27 + k];
+        if (lmk_lam) unpack3(o + 30, lmk_lam + (size_t)q * 9);
     }
     return GBP_OK;
 }

@@ -19,9 +19,9 @@
 //     (workgroup, tile, rank) -- independent of which wave ran which tile and of timing.  Within a rank round
 //     every lane targets a different camera, so the LDS ds_add_f64 is a plain read-modify-write.
 //
-// HBM traffic per sweep: F*(47 read + 36 written doubles + 12 B of indices) + L*(24 read + 12 written doubles)
-// + the workgroup tables (256 * C * 27 doubles written and read once) -- below the "algorithmic" 1072 B per
-// factor of SURVEY.md 8d, which assumed a second pass over the messages.
+// HBM traffic per sweep: F*(26 read + 15 written doubles + 12 B of indices) + L*(24 read + 12 written doubles)
+// + the workgroup tables (256 * C * 27 doubles written and read once) -- a third of the "algorithmic" 1072 B per
+// factor of SURVEY.md 8d, which assumed dense message precisions and a second pass over the messages.
 //
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc does not fit the LDS (C > ~540) the
@@ -92,14 +92,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 #pragma unroll
         for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) stage[j] = (j * 64 + lane < nrec) ? lsrc[j * 64 + lane] : 0.0;
 
-        // everything the factor streams + its camera record: one round trip (the SIMD's second wave covers it);
-        // the cavities (belief minus this factor's old message) are formed at once, which frees 21 + 6 + 6 doubles
+        // everything the factor streams + its camera record: one round trip (the SIMD's second wave covers it)
         unsigned meta = 0;
         int st = 0;
-        double x0[9], z[2], avar = p.sigma2, eC[6], eL[3], muC[6];
-        double ceC[6], clC[21], ceL[3], clL[6];
+        double x0[9], z[2], avar = p.sigma2, eC[6], eL[3], WC[3], VL[3], muC[6], ceC[6], clC[21];
         if (active) {
-            double MC[21], ML[6], etaC[6], lamC[21];
             meta = p.meta[slot];
             st = p.state[slot];
 #pragma unroll
@@ -109,18 +106,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 #pragma unroll
             for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
 #pragma unroll
-            for (int k = 0; k < 21; ++k) MC[k] = p.msg[msg_at(slot, ROW_MC + k)];
-#pragma unroll
             for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ML[k] = p.msg[msg_at(slot, ROW_ML + k)];
-            load_cam_record(p.cbel + (size_t)(meta >> META_LMK_BITS) * CAMREC, etaC, lamC, muC);
+            for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ceC[k] = etaC[k] - eC[k];
+            for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+            load_cam_record(p.cbel + (size_t)(meta >> META_LMK_BITS) * CAMREC, ceC, clC, muC);
 #pragma unroll
-            for (int k = 0; k < 21; ++k) clC[k] = lamC[k] - MC[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) clL[k] = -ML[k];
+            for (int k = 0; k < 6; ++k) ceC[k] -= eC[k];
         }
         const int cam = (int)(meta >> META_LMK_BITS);
 
@@ -128,13 +121,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 #pragma unroll
         for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) wl[j * 64 + lane] = stage[j];
         wave_lds_sync();
-        double muL[3];
+        double muL[3], ceL[3], clL[6];
         if (active) {
             const double *src = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC;
 #pragma unroll
             for (int k = 0; k < 3; ++k) ceL[k] = src[LR_BEL + k] - eL[k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) clL[k] += src[LR_BEL + 3 + k];
+            for (int k = 0; k < 6; ++k) clL[k] = src[LR_BEL + 3 + k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) muL[k] = src[LR_MU + k];
         }
@@ -142,11 +135,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 
         double MCn[21];
         if (active) {
-            Lin L;
-            const bool relin = factor_prepare<LOSS>(p, x0, z, st, avar, muC, muL, L);
-            double eLn[3], MLn[6];
-            message_to_landmark_cavity(L, ceC, clC, eL, eLn, MLn);
-            message_to_camera_cavity(L, ceL, clL, eC, MCn);
+            double MLn[6];
+            const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, ceC, clC, ceL, clL, eC, eL, WC, VL, MCn, MLn);
             if (relin) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
@@ -154,11 +144,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 #pragma unroll
             for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
 #pragma unroll
-            for (int k = 0; k < 21; ++k) p.msg[msg_at(slot, ROW_MC + k)] = MCn[k];
+            for (int k = 0; k < 3; ++k) { p.msg[msg_at(slot, ROW_EL + k)] = eL[k]; wl[lane * 9 + k] = eL[k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { p.msg[msg_at(slot, ROW_EL + k)] = eLn[k]; wl[lane * 9 + k] = eLn[k]; }
+            for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { p.msg[msg_at(slot, ROW_ML + k)] = MLn[k]; wl[lane * 9 + 3 + k] = MLn[k]; }
+            for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
             p.state[slot] = st;
             if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
         }

@@ -12,12 +12,13 @@
 //     lin[tile][12][64]   rows 0-8 x0 = linearisation point (t, w, y)      Factor.linpoint      gbp.py:231
 //                         rows 9-10 z  = measurement                        Factor.measurement   gbp.py:233
 //                         row  11  adaptive noise variance (loss != none)   gbp.py:242
-//     msg[tile][36][64]   rows 0-5 / 6-26  message to the camera  eta / Lambda packed   Factor.messages[0]
-//                         rows 27-29 / 30-35 message to the landmark eta / Lambda packed Factor.messages[1]
+//     msg[tile][16][64]   rows 0-5 eta of the message to the camera, rows 6-8 eta of the message to the landmark,
+//                         rows 9-11 / 12-14 the 2x2 cores W / V of the two message precisions (Lambda = J^T Q J with
+//                         J at x0: gbp_math.hpp rank2_update), row 15 pad            Factor.messages  gbp.py:222
 //     state[slot] int32 = iters_since_relin << 12 | rank << 2 | robust << 1 | damped     gbp.py:245-249
 //     meta[slot] uint32 = camera index << 8 | landmark's position inside its tile
 // so a wave's access is one contiguous 1 KB line per row pair and a tile's whole working set is one
-// 18 KB + 6 KB block.  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
+// 8 KB + 6 KB block (the reference's dense messages would be 27 KB: Lambda 6x6 + 3x3 per factor).  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
 // stride-F arrays reach 3.9 TB/s at 4 waves/CU, as tile-contiguous blocks 5.4 TB/s.)
 // Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt from x0 and z
 // every sweep (2x9 Jacobian ~ 150 flops versus 720 bytes of traffic).
@@ -36,9 +37,9 @@ namespace gbp {
 
 constexpr int WTILE = 64;         // slots per tile = lanes per wavefront
 constexpr int TILE_LMKS = 24;     // most landmarks a tile owns
-constexpr int LIN_ROWS = 12, MSG_ROWS = 36;
+constexpr int LIN_ROWS = 12, MSG_ROWS = 16;
 constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_AVAR = 11;
-constexpr int ROW_EC = 0, ROW_MC = 6, ROW_EL = 27, ROW_ML = 30;
+constexpr int ROW_EC = 0, ROW_EL = 6, ROW_WC = 9, ROW_VL = 12;
 constexpr int LREC = 24;          // doubles per landmark record
 constexpr int LR_BEL = 0, LR_MU = 9, LR_PRIOR = 12, LR_ROWS = 21;
 constexpr int CAMREC = 34;        // doubles per camera record
@@ -82,16 +83,16 @@ GBP_DEV int state_pack(int iters, int rank, bool robust, bool damped)
     return (int)(((unsigned)iters << STATE_SHIFT) | ((unsigned)rank << 2) | (robust ? 2u : 0u) | (damped ? 1u : 0u));
 }
 
-// Per-factor front half of FactorGraph.synchronous_iteration (gbp.py:86-92): robustify (gbp.py:296-332)
-// -> relinearise test (gbp.py:64-80) -> damping switch (gbp.py:50-51) -> linearisation at the chosen point.
-// Returns true when the factor relinearised (x0 was replaced by the belief means).
+// Per-factor front of FactorGraph.synchronous_iteration (gbp.py:86-92): robustify (gbp.py:296-332), relinearisation
+// test (gbp.py:64-80) and damping switch (gbp.py:50-51).  Returns true when the factor must relinearise at the belief
+// means; `d` is the eta damping for this sweep.  x0 is NOT modified here (the old point is still needed to rebuild the
+// factor's old messages).
 template <int LOSS>
-GBP_DEV bool factor_prepare(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
-                            const double (&muC)[6], const double (&muL)[3], Lin &L)
+GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double (&z)[2], int &st, double &avar,
+                           const double (&muC)[6], const double (&muL)[3], double &d)
 {
     int iters = state_iters(st);
     bool robust = (st & 2) != 0, damped = (st & 1) != 0;
-
     if (LOSS != 0 && p.robustify) {
         double h0[2];
         project(x0, p.K, h0);
@@ -99,8 +100,7 @@ GBP_DEV bool factor_prepare(const Params &p, double (&x0)[9], const double (&z)[
     } else if (p.robustify) {
         avar = p.sigma2;                       // loss None: adaptive = gauss_noise_var  gbp.py:302-303
     }
-
-    bool relinearised = false;
+    bool relin = false;
     if (p.local_relin) {
         double d2 = 0.0;
 #pragma unroll
@@ -108,21 +108,24 @@ GBP_DEV bool factor_prepare(const Params &p, double (&x0)[9], const double (&z)[
 #pragma unroll
         for (int i = 0; i < 3; ++i) d2 += (x0[6 + i] - muL[i]) * (x0[6 + i] - muL[i]);
         if (sqrt(d2) > p.beta && iters >= p.min_linear) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) x0[i] = muC[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
             iters = 0;
             damped = false;
-            relinearised = true;
+            relin = true;
         } else {
             iters += 1;
         }
         if (iters == p.num_undamped) damped = true;      // gbp.py:50-51 (equality, not >=)
     }
-    L.d = p.local_relin ? (damped ? p.eta_damping : 0.0) : p.eta_damping;   // gbp.py:52-54
-    L.s = 1.0 / avar;
+    d = p.local_relin ? (damped ? p.eta_damping : 0.0) : p.eta_damping;   // gbp.py:52-54
+    st = state_pack(iters, state_rank(st), robust, damped);
+    return relin;
+}
 
+// Factor.compute_factor in compact form (gbp.py:267-294): J = [Jc | Jl], rho = J x0 + z - h(x0), s = 1 / adaptive var
+GBP_DEV void factor_linearise(const Params &p, const double (&x0)[9], const double (&z)[2], double avar, double d, Lin &L)
+{
+    L.d = d;
+    L.s = 1.0 / avar;
     double h[2];
     linearise(x0, p.K, L.Jc, L.Jl, h);
 #pragma unroll
@@ -134,9 +137,46 @@ GBP_DEV bool factor_prepare(const Params &p, double (&x0)[9], const double (&z)[
         for (int i = 0; i < 3; ++i) acc += L.Jl[r][i] * x0[6 + i];
         L.rho[r] = acc + z[r] - h[r];
     }
-    st = state_pack(iters, state_rank(st), robust, damped);
-    return relinearised;
 }
+
+// One factor's sweep in registers (gbp.py:82-84, 64-80, 46-54, 334-373).
+//   in : x0, z, state, adaptive variance, means of the two beliefs,
+//        ceC = eta_C - e_C(old), clC = Lambda_C,  ceL = eta_L - e_L(old), clL = Lambda_L   (cl* are consumed),
+//        old message etas eC / eL and old cores WC / VL
+//   out: new eC / eL / WC / VL (both messages from the OLD ones, gbp.py:371-373), dense new Lambda MCn / MLn for the
+//        belief sums, x0 / state / avar updated; returns true when the factor relinearised (x0 changed).
+template <int LOSS>
+GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
+                         const double (&muC)[6], const double (&muL)[3],
+                         const double (&ceC)[6], double (&clC)[21], const double (&ceL)[3], double (&clL)[6],
+                         double (&eC)[6], double (&eL)[3], double (&WC)[3], double (&VL)[3],
+                         double (&MCn)[21], double (&MLn)[6])
+{
+    double d;
+    const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
+    Lin L;
+    factor_linearise(p, x0, z, avar, d, L);
+    // cavities: belief minus this factor's OLD message, whose precision lives in the span of the OLD Jacobian
+    rank2_update<6>(clC, L.Jc[0], L.Jc[1], WC, -1.0);
+    rank2_update<3>(clL, L.Jl[0], L.Jl[1], VL, -1.0);
+    if (relin) {                                           // gbp.py:75-78: linearise again at the belief means
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x0[i] = muC[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
+        factor_linearise(p, x0, z, avar, d, L);
+    }
+    double eLn[3];
+    message_to_landmark_cavity(L, ceC, clC, eL, eLn, MLn, VL);
+    message_to_camera_cavity(L, ceL, clL, eC, MCn, WC);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eL[i] = eLn[i];
+    return relin;
+}
+
+// The dense messages of a slot (for the belief sums of the general path and the parity views): the precisions are
+// rebuilt from their cores at the stored linearisation point.
+GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6]);
 
 GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], double (&lam)[21], double (&mu)[6])
 {
@@ -173,35 +213,34 @@ __global__ __launch_bounds__(BLOCK, GBP_KF_WAVES) void k_factor(Params p)
     if (slot >= p.T * WTILE) return;
     int cam, lmk;
     if (!slot_info(p, slot, cam, lmk)) return;
-    double x0[9], z[2], eC[6], MC[21], eL[3], ML[6];
+    double x0[9], z[2], eC[6], eL[3], WC[3], VL[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
     z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
 #pragma unroll
     for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) MC[k] = p.msg[msg_at(slot, ROW_MC + k)];
-#pragma unroll
     for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ML[k] = p.msg[msg_at(slot, ROW_ML + k)];
+    for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
     int st = p.state[slot];
     double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
-    double etaC[6], lamC[21], muC[6], etaL[3], lamL[6], muL[3];
+    double etaC[6], lamC[21], muC[6], ceL[3], lamL[6], muL[3];
     load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, lamC, muC);
     const double *lr = p.lrec + (size_t)lmk * LREC;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) etaL[k] = lr[LR_BEL + k];
+    for (int k = 0; k < 3; ++k) ceL[k] = lr[LR_BEL + k] - eL[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) etaC[k] -= eC[k];
 
-    Lin L;
-    const bool relin = factor_prepare<LOSS>(p, x0, z, st, avar, muC, muL, L);
-    double eLn[3], MLn[6], MCn[21];
-    message_to_landmark(L, etaC, lamC, eC, MC, eL, eLn, MLn);
-    message_to_camera(L, etaL, lamL, eL, ML, eC, MCn);
+    double MCn[21], MLn[6];
+    const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC, ceL, lamL, eC, eL, WC, VL, MCn, MLn);
 
     if (relin) {
 #pragma unroll
@@ -210,13 +249,35 @@ __global__ __launch_bounds__(BLOCK, GBP_KF_WAVES) void k_factor(Params p)
 #pragma unroll
     for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) p.msg[msg_at(slot, ROW_MC + k)] = MCn[k];
+    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_EL + k)] = eL[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_EL + k)] = eLn[k];
+    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_ML + k)] = MLn[k];
+    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
     p.state[slot] = st;
     if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
+}
+
+GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6])
+{
+    double x0[9], Jc[2][6], Jl[2][3], h[2], WC[3], VL[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+    linearise(x0, p.K, Jc, Jl, h);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) MC[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ML[k] = 0.0;
+    rank2_update<6>(MC, Jc[0], Jc[1], WC, 1.0);
+    rank2_update<3>(ML, Jl[0], Jl[1], VL, 1.0);
 }
 
 // ------------------------------------------------------------------ general sweep, stage 2 --
@@ -230,8 +291,12 @@ GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
     for (int k = 0; k < 9; ++k) acc[k] = lr[LR_PRIOR + k];
     const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
     for (int s = rows.x; s < rows.y; ++s) {
+        double eC[6], MC[21], eL[3], ML[6];
+        dense_messages(p, s, eC, MC, eL, ML);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] += p.msg[msg_at(s, ROW_EL + k)];
+        for (int k = 0; k < 3; ++k) acc[k] += eL[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[3 + k] += ML[k];
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) lr[LR_BEL + k] = acc[k];
@@ -266,8 +331,12 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restr
     const int e1 = p.cptr[c + 1];
     for (int e = p.cptr[c] + threadIdx.x; e < e1; e += BLOCK) {
         const int s = p.cadj[e];
+        double eC[6], MC[21], eL[3], ML[6];
+        dense_messages(p, s, eC, MC, eL, ML);
 #pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] += p.msg[msg_at(s, ROW_EC + k)];
+        for (int k = 0; k < 6; ++k) acc[k] += eC[k];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) acc[6 + k] += MC[k];
     }
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -401,6 +470,24 @@ __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *_
 #pragma unroll
         for (int b = 0; b < 9; ++b) lam_out[(size_t)i * 81 + a * 9 + b] = s * (J[0][a] * J[0][b] + J[1][a] * J[1][b]);
     }
+}
+
+// dense messages of a list of slots for the parity views (Factor.messages gbp.py:222): eta 6 | Lambda 21 packed | eta 3 | Lambda 6 packed
+__global__ __launch_bounds__(BLOCK) void k_export_messages(Params p, const int *__restrict__ slots, int n, double *__restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double eC[6], MC[21], eL[3], ML[6];
+    dense_messages(p, slots[i], eC, MC, eL, ML);
+    double *o = out + (size_t)i * 36;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = eC[k];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) o[6 + k] = MC[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[27 + k] = eL[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[30 + k] = ML[k];
 }
 
 // Sigma = Lambda^-1 for the covariance view (VariableNode.Sigma gbp.py:192)

@@ -22,7 +22,8 @@
 //   * S and T are symmetric positive definite (factor block + cavity >= prior), so the general LU
 //     inverse of the reference is replaced by an unpivoted LDL^T on packed upper storage, and only
 //     the forward substitution is needed: X^T S^-1 Y = (L^-1 X)^T D^-1 (L^-1 Y).
-//   * symmetric matrices are stored packed (upper triangle, row-major): 6x6 -> 21, 3x3 -> 6.
+//   * symmetric matrices are stored packed (upper triangle, row-major): 6x6 -> 21, 3x3 -> 6;
+//   * message precisions are stored as their 2x2 cores (M = J^T Q J): 3 doubles instead of 21 / 6 (rank2_update).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -251,7 +252,7 @@ struct Lin {
 // The forward substitutions of Jc^T and u ride along with the LDL^T elimination (augmented columns) and the
 // 2x2 quadratic forms are accumulated pivot by pivot, so nothing but the shrinking trailing block stays live.
 GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], double (&clamC)[21],
-                                        const double (&eLold)[3], double (&eLnew)[3], double (&MLnew)[6])
+                                        const double (&eLold)[3], double (&eLnew)[3], double (&MLnew)[6], double (&Vcore)[3])
 {
     const double s = L.s;
     double y0[6], y1[6], u[6];
@@ -278,6 +279,7 @@ GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], 
         }
     }
     const double V00 = s - s * s * H00, V01 = -(s * s) * H01, V11 = s - s * s * H11;
+    Vcore[0] = V00; Vcore[1] = V01; Vcore[2] = V11;
     const double r0 = s * (L.rho[0] - k0), r1 = s * (L.rho[1] - k1);
     double VJ0[3], VJ1[3];
 #pragma unroll
@@ -298,7 +300,7 @@ GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], 
 //   S = s Jl^T Jl + clamL,  g = s Jl^T rho + cetaL
 //   M_C' = Jc^T (sI - s^2 Jl S^-1 Jl^T) Jc,  e_C' = (1-d) s Jc^T (rho - Jl S^-1 g) + d e_C   (eC in: old, out: new)
 GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], double (&clamL)[6],
-                                      double (&eC)[6], double (&MCnew)[21])
+                                      double (&eC)[6], double (&MCnew)[21], double (&Wcore)[3])
 {
     const double s = L.s;
     double y0[3], y1[3], g[3];
@@ -325,6 +327,7 @@ GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], do
         }
     }
     const double W00 = s - s * s * G00, W01 = -(s * s) * G01, W11 = s - s * s * G11;
+    Wcore[0] = W00; Wcore[1] = W01; Wcore[2] = W11;
     const double r0 = s * (L.rho[0] - k0), r1 = s * (L.rho[1] - k1);
     double WJ0[6], WJ1[6];
 #pragma unroll
@@ -340,29 +343,21 @@ GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], do
     }
 }
 
-// Belief / old-message interfaces of the two messages (general kernels): form the cavities, then as above.
-GBP_DEV void message_to_landmark(const Lin &L, const double (&etaC)[6], const double (&lamC)[21],
-                                 const double (&eC)[6], const double (&MC)[21], const double (&eLold)[3],
-                                 double (&eLnew)[3], double (&MLnew)[6])
+// A message precision never leaves the span of its Jacobian block: M = J^T Q J with a symmetric 2x2 core Q (W for the
+// camera message, V for the landmark message; Lambda is never damped, gbp.py:368).  Only Q (3 doubles) is stored per
+// message instead of the packed 21 / 6; the dense matrix is rebuilt from the Jacobian at the linearisation point the
+// message was computed with.   T += sign * J^T Q J   on packed upper storage, J given by its two rows.
+template <int N>
+GBP_DEV void rank2_update(double (&T)[Sym<N>::size], const double (&j0)[N], const double (&j1)[N], const double (&Q)[3],
+                          double sign)
 {
-    double ce[6], cl[21];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ce[i] = etaC[i] - eC[i];
+    for (int j = 0; j < N; ++j) {
+        const double a = sign * (Q[0] * j0[j] + Q[1] * j1[j]);
+        const double b = sign * (Q[1] * j0[j] + Q[2] * j1[j]);
 #pragma unroll
-    for (int i = 0; i < 21; ++i) cl[i] = lamC[i] - MC[i];
-    message_to_landmark_cavity(L, ce, cl, eLold, eLnew, MLnew);
-}
-
-GBP_DEV void message_to_camera(const Lin &L, const double (&etaL)[3], const double (&lamL)[6],
-                               const double (&eLold)[3], const double (&MLold)[6],
-                               double (&eC)[6], double (&MCnew)[21])
-{
-    double ce[3], cl[6];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ce[i] = etaL[i] - eLold[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) cl[i] = lamL[i] - MLold[i];
-    message_to_camera_cavity(L, ce, cl, eC, MCnew);
+        for (int i = 0; i <= j; ++i) T[Sym<N>::at(i, j)] += j0[i] * a + j1[i] * b;
+    }
 }
 
 // max over all 81 signed entries of Lambda_f = s J^T J (np.max(factor.factor.lam), gbp_ba.py:31)
