@@ -173,9 +173,12 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
     return GBP_OK;
 }
 
-// one synchronous_iteration's device work up to (and including) this rank's camera partial sums
-static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial)
+// one synchronous_iteration's device work up to (and including) this rank's camera partial sums; with finish != 0 the
+// camera beliefs are completed as well (single GPU) and *finished tells the caller so
+static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish = 0,
+                       bool *finished = nullptr)
 {
+    if (finished) *finished = false;
     if (with_messages && h->fused.enabled) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
@@ -184,8 +187,9 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
             e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
             h->ev_used += 2;
         }
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, e0, e1);
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1);
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (finished) *finished = finish != 0;
         return GBP_OK;
     }
     if (with_messages) CHK(launch_factor_stage(h, robustify, local_relin));
@@ -547,8 +551,9 @@ int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t loca
     ENTER(h);
     if (n_iters < 0) return fail(GBP_EINVAL, "n_iters < 0");
     for (int it = 0; it < n_iters; ++it) {
-        CHK(sweep_begin(h, 1, robustify, local_relin, h->d_partial));
-        CHK(launch_cam_finish(h, h->d_partial, 1, 0));
+        bool finished = false;
+        CHK(sweep_begin(h, 1, robustify, local_relin, h->d_partial, 1, &finished));
+        if (!finished) CHK(launch_cam_finish(h, h->d_partial, 1, 0));
     }
     h->has_beliefs = true;
     return GBP_OK;

@@ -40,7 +40,7 @@ constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][24]
 static_assert(TILE_LMKS * LREC <= WAVE_LDS_DOUBLES, "landmark records of a tile must fit the wave scratch");
 
 struct FusedArgs {
-    double *block_partials;     // [n_blocks][C*27]
+    double *block_partials;     // [C][n_blocks][27]
     int acc_doubles;            // C*27
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase
 };
@@ -193,27 +193,64 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    double *out = a.block_partials + (size_t)blockIdx.x * a.acc_doubles;
-    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) out[i] = acc[i];
+    // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
+    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
+        const int c = i / 27, k = i - c * 27;
+        a.block_partials[((size_t)c * gridDim.x + blockIdx.x) * 27 + k] = acc[i];
+    }
 }
 
-// partial[e] = sum over workgroups (fixed order) of block_partials[b][e]
-__global__ __launch_bounds__(BLOCK) void k_cam_reduce_blocks(const double *__restrict__ block_partials, int n_blocks,
-                                                             int n, double *__restrict__ partial)
+// One workgroup per camera: partial[c] = sum over the per-workgroup tables (fixed tree -> bitwise reproducible).  With
+// finish != 0 (single GPU: nothing to exchange) the camera belief is completed in place: prior + sum, 6x6 solve
+// (VariableNode.update_belief gbp.py:182-193), which saves a dependent launch.
+__global__ __launch_bounds__(BLOCK) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
+                                                           double *__restrict__ partial, int finish)
 {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= n) return;
-    double s = 0.0;
-    int b = 0;
-    for (; b + 8 <= n_blocks; b += 8) {
-        double v[8];
+    __shared__ double red[BLOCK / 64][27];
+    __shared__ double tot[27];
+    const int c = blockIdx.x;
+    double acc[27];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = block_partials[(size_t)(b + j) * n + e];
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
+        const double *src = block_partials + ((size_t)c * n_blocks + b) * 27;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
+        for (int k = 0; k < 27; ++k) acc[k] += src[k];
     }
-    for (; b < n_blocks; ++b) s += block_partials[(size_t)b * n + e];
-    partial[e] = s;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        acc[k] = v;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) s += red[w][threadIdx.x];
+        partial[(size_t)c * 27 + threadIdx.x] = s;
+        tot[threadIdx.x] = s + p.cprior[(size_t)c * 27 + threadIdx.x];
+    }
+    if (!finish) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *rec = p.cbel + (size_t)c * CAMREC;
+        double eta[6], lam[21], mu[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { eta[k] = tot[k]; rec[CAM_ETA + k] = tot[k]; }
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { lam[k] = tot[6 + k]; rec[CAM_ETA + 6 + k] = tot[6 + k]; }
+        spd_solve<6>(lam, eta, mu);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
+        rec[33] = 0.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------ host --
@@ -278,7 +315,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 
 // returns 0 or a hipError_t value
 inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int local_relin, double *partial, hipStream_t stream,
-                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     Params p = p0;
     p.robustify = robustify; p.local_relin = local_relin;
@@ -291,8 +328,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     }
     if (e1) (void)hipEventRecord(e1, stream);
     if (pl.n_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
-    hipLaunchKernelGGL(k_cam_reduce_blocks, dim3((pl.args.acc_doubles + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream,
-                       pl.args.block_partials, pl.n_blocks, pl.args.acc_doubles, partial);
+    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(BLOCK), 0, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);
     return (int)hipGetLastError();
 }
 

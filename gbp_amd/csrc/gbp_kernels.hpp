@@ -125,7 +125,7 @@ GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double 
 GBP_DEV void factor_linearise(const Params &p, const double (&x0)[9], const double (&z)[2], double avar, double d, Lin &L)
 {
     L.d = d;
-    L.s = 1.0 / avar;
+    L.s = rcp(avar);
     double h[2];
     linearise(x0, p.K, L.Jc, L.Jl, h);
 #pragma unroll

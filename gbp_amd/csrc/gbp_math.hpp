@@ -31,6 +31,21 @@ namespace gbp {
 
 #define GBP_DEV __device__ __forceinline__
 
+// 1/x for the pivots and depths of this path (normal, far from over/underflow): hardware seed (v_rcp_f64, ~26 bits)
+// + two Newton steps = full double precision (<= 1 ulp) in 5 dependent instructions; the IEEE division sequence
+// (v_div_scale / v_div_fmas / v_div_fixup) is twice as long and sits on every elimination's critical path.
+GBP_DEV double rcp(double x)
+{
+#ifdef GBP_IEEE_DIV
+    return 1.0 / x;
+#else
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#endif
+}
+
 template <int N>
 struct Sym {
     static constexpr int size = N * (N + 1) / 2;
@@ -49,7 +64,7 @@ GBP_DEV void ldl_factor(double (&a)[Sym<N>::size], double (&invd)[N])
 {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const double r = 1.0 / a[Sym<N>::at(k, k)];
+        const double r = rcp(a[Sym<N>::at(k, k)]);
         invd[k] = r;
 #pragma unroll
         for (int i = k + 1; i < N; ++i) {
@@ -166,8 +181,8 @@ GBP_DEV Rot rodrigues(double w0, double w1, double w2)
 #else
     sincos_theta(th, sn, cs);
 #endif
-    const double ith2 = 1.0 / th2;
-    const double a = sn / th;
+    const double ith2 = rcp(th2);
+    const double a = sn * rcp(th);
     const double b = (1.0 - cs) * ith2;
     // R = I + a w^ + b w^ w^,  w^ w^ = w w^T - theta^2 I  (diagonal written without cancellation)
     o.r[0][0] = 1.0 - b * (w1 * w1 + w2 * w2);
@@ -202,7 +217,7 @@ GBP_DEV void linearise(const double (&x)[9], const Intrinsics &K, double (&Jc)[2
     const double p0 = R.r[0][0] * y0 + R.r[0][1] * y1 + R.r[0][2] * y2 + x[0];
     const double p1 = R.r[1][0] * y0 + R.r[1][1] * y1 + R.r[1][2] * y2 + x[1];
     const double p2 = R.r[2][0] * y0 + R.r[2][1] * y1 + R.r[2][2] * y2 + x[2];
-    const double iz = 1.0 / p2;
+    const double iz = rcp(p2);
     h[0] = (K.fx * p0 + K.cx * p2) * iz;
     h[1] = (K.fy * p1 + K.cy * p2) * iz;
     // J_p K = [[fx/Z, 0, cx/Z - X/Z^2], [0, fy/Z, cy/Z - Y/Z^2]];  cx/Z - X/Z^2 == -fx p0 / Z^2
@@ -266,7 +281,7 @@ GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], 
     double H00 = 0.0, H01 = 0.0, H11 = 0.0, k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const double r = 1.0 / clamC[Sym<6>::at(k, k)];
+        const double r = rcp(clamC[Sym<6>::at(k, k)]);
         const double t0 = y0[k] * r, t1 = y1[k] * r;
         H00 += t0 * y0[k]; H01 += t0 * y1[k]; H11 += t1 * y1[k];
         k0 += t0 * u[k]; k1 += t1 * u[k];
@@ -314,7 +329,7 @@ GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], do
     double G00 = 0.0, G01 = 0.0, G11 = 0.0, k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double r = 1.0 / clamL[Sym<3>::at(k, k)];
+        const double r = rcp(clamL[Sym<3>::at(k, k)]);
         const double t0 = y0[k] * r, t1 = y1[k] * r;
         G00 += t0 * y0[k]; G01 += t0 * y1[k]; G11 += t1 * y1[k];
         k0 += t0 * g[k]; k1 += t1 * g[k];
