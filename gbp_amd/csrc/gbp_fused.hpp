@@ -37,6 +37,8 @@ namespace gbp {
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int WAT_WAVES = 8;
 constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][24] landmark records, then [64][9] messages
+constexpr int LPRI = 10;                            // prior 9 | {row0,row1}: what the tail of a tile needs per landmark
+constexpr int WAVE_PRIOR_DOUBLES = TILE_LMKS * LPRI;
 static_assert(TILE_LMKS * LREC <= WAVE_LDS_DOUBLES, "landmark records of a tile must fit the wave scratch");
 
 struct FusedArgs {
@@ -66,117 +68,141 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *acc = smem;                                              // [C][27]
-    double *wl = smem + ((a.acc_doubles + 1) & ~1) + (threadIdx.x >> 6) * WAVE_LDS_DOUBLES;
-    int *ctl = reinterpret_cast<int *>(smem + ((a.acc_doubles + 1) & ~1) + NWAVES * WAVE_LDS_DOUBLES);   // {next, done}
+    const int acc_even = (a.acc_doubles + 1) & ~1, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *wl = smem + acc_even + wave * WAVE_LDS_DOUBLES;
+    double *wp = smem + acc_even + NWAVES * WAVE_LDS_DOUBLES + wave * WAVE_PRIOR_DOUBLES;      // [24][10] prior | rows
+    int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES));   // {next, done}
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
     const int tb = blk_begin[blockIdx.x], ntl = blk_begin[blockIdx.x + 1] - tb;
 
+    // The landmark beliefs of a tile (LDS work, no loads) are formed one iteration LATE, after the next tile's loads have
+    // been issued, so that the wave has HBM requests in flight meanwhile.  Nothing is carried in vector registers: the
+    // tile's landmark messages and priors wait in the wave's LDS scratch, which the next tile overwrites only afterwards.
+    bool pend = false;
+    int q_t = 0, q_l0 = 0, q_nl = 0;
+
     for (;;) {
         int ti = 0;
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
-        if (ti >= ntl) break;
-        const int t = tb + ti;
-        const int4 td = tiles[t];
+        const bool valid = ti < ntl;
+        const int t = tb + (valid ? ti : 0);
+        int4 td = make_int4(0, 0, 0, 0);
+        if (valid) td = tiles[t];
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
         const int slot = t * WTILE + lane;
 
         // the tile's landmark records (belief | mean | prior | rows) are one contiguous run: the wave fetches it whole
-        const int nrec = max(nl, 1) * LREC;                // chunk tiles stage the over-sized landmark td.x
+        const int nrec = valid ? max(nl, 1) * LREC : 0;    // chunk tiles stage the over-sized landmark td.x
         const double *lsrc = p.lrec + (size_t)l0 * LREC;
         double stage[WAVE_LDS_DOUBLES / 64];
 #pragma unroll
         for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) stage[j] = (j * 64 + lane < nrec) ? lsrc[j * 64 + lane] : 0.0;
 
-        // everything the factor streams + its camera record: one round trip (the SIMD's second wave covers it)
-        unsigned meta = 0;
-        int st = 0;
+        // everything the factor streams
+        // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
+        //  copies that would make the wave wait for them before the tail below)
         double x0[9], z[2], avar = p.sigma2, eC[6], eL[3], WC[3], VL[3], muC[6], ceC[6], clC[21];
-        if (active) {
-            meta = p.meta[slot];
-            st = p.state[slot];
+        const unsigned meta = p.meta[slot];
+        int st = p.state[slot];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-            z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
-            if (LOSS != 0) avar = p.lin[lin_at(slot, ROW_AVAR)];
+        for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+        z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
+        if (LOSS != 0) avar = p.lin[lin_at(slot, ROW_AVAR)];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
+        for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+        for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
+        for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
-            load_cam_record(p.cbel + (size_t)(meta >> META_LMK_BITS) * CAMREC, ceC, clC, muC);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ceC[k] -= eC[k];
-        }
-        const int cam = (int)(meta >> META_LMK_BITS);
+        for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+        asm volatile("" ::: "memory");
 
-        // landmark records -> wave scratch -> the lanes of their factors
-#pragma unroll
-        for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) wl[j * 64 + lane] = stage[j];
-        wave_lds_sync();
-        double muL[3], ceL[3], clL[6];
-        if (active) {
-            const double *src = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ceL[k] = src[LR_BEL + k] - eL[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) clL[k] = src[LR_BEL + 3 + k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) muL[k] = src[LR_MU + k];
-        }
-        wave_lds_sync();                                   // scratch is free again
-
-        double MCn[21];
-        if (active) {
-            double MLn[6];
-            const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, ceC, clC, ceL, clL, eC, eL, WC, VL, MCn, MLn);
-            if (relin) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { p.msg[msg_at(slot, ROW_EL + k)] = eL[k]; wl[lane * 9 + k] = eL[k]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-            p.state[slot] = st;
-            if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
-        }
-        wave_lds_sync();
-
-        // landmark beliefs of the tile: prior + messages in adj_factors order (gbp.py:182-193)
-        if (lane < nl && !(a.dbg & 4)) {
-            const double *lr = p.lrec + (size_t)(l0 + lane) * LREC;   // prior + rows again (L2 hit): not worth 20 registers
+        // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
+        if (pend && lane < q_nl && !(a.dbg & 4)) {
+            const double *pr = wp + lane * LPRI;
             double b[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) b[k] = lr[LR_PRIOR + k];
-            const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
-            const int row0 = rows.x - t * WTILE, row1 = rows.y - t * WTILE;
+            for (int k = 0; k < 9; ++k) b[k] = pr[k];
+            const int2 rows = *reinterpret_cast<const int2 *>(pr + 9);
+            const int row0 = rows.x - q_t * WTILE, row1 = rows.y - q_t * WTILE;
             for (int r = row0; r < row1; ++r) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) b[k] += wl[r * 9 + k];
             }
             double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
-            double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(l0 + lane) * LREC);
+            double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(q_l0 + lane) * LREC);
             dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
             dst[2] = make_double2(b[4], b[5]); dst[3] = make_double2(b[6], b[7]);
             spd_solve<3>(lam, eta, mu);
             dst[4] = make_double2(b[8], mu[0]); dst[5] = make_double2(mu[1], mu[2]);
         }
+        asm volatile("" ::: "memory");
 
-        // ticket: camera accumulation strictly in tile order
+        // the camera record of this tile's factors: a gather that needs `meta` (L2 hits)
+        const int cam = active ? (int)(meta >> META_LMK_BITS) : 0;
+        load_cam_record(p.cbel + (size_t)cam * CAMREC, ceC, clC, muC);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ceC[k] -= eC[k];
+        asm volatile("" ::: "memory");
+
+        if (!valid) break;
+
+        // landmark records -> wave scratch -> the lanes of their factors; priors | rows -> wp for the tail
+#pragma unroll
+        for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) wl[j * 64 + lane] = stage[j];
+        wave_lds_sync();
+        double muL[3], clL[6];
+        if (active) {
+            const double *src = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) clL[k] = src[LR_BEL + 3 + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) muL[k] = src[LR_MU + k];
+        }
+        if (lane < nl) {                                   // prior | rows of the tile's landmarks, kept for the tail
+            int o = lane;
+            asm volatile("" : "+v"(o));                    // (keeps the compiler from hoisting five addresses out of the loop and spilling them)
+            const double2 *src = reinterpret_cast<const double2 *>(wl + o * LREC + LR_PRIOR);
+            double2 *dst = reinterpret_cast<double2 *>(wp + o * LPRI);
+#pragma unroll
+            for (int k = 0; k < LPRI / 2; ++k) dst[k] = src[k];
+        }
+        wave_lds_sync();
+
+        double MCn[21];
+        if (active) {
+            double MLn[6];
+            const double *lbel = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC + LR_BEL;   // still intact: messages go in below
+            const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, ceC, clC,
+                                                 [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
+                                                 clL, eC, eL, WC, VL, MCn, MLn);
+            int sslot = slot;
+            asm volatile("" : "+v"(sslot));             // store addresses are recomputed here, not kept alive (and spilled) through the maths
+            if (relin) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) p.lin[lin_at(sslot, ROW_X0 + k)] = x0[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.msg[msg_at(sslot, ROW_EC + k)] = eC[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { p.msg[msg_at(sslot, ROW_EL + k)] = eL[k]; wl[lane * 9 + k] = eL[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p.msg[msg_at(sslot, ROW_WC + k)] = WC[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p.msg[msg_at(sslot, ROW_VL + k)] = VL[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
+            p.state[sslot] = st;
+            if (LOSS != 0) p.lin[lin_at(sslot, ROW_AVAR)] = avar;
+        }
+        wave_lds_sync();
+        // camera accumulation strictly in tile order
         if (!(a.dbg & 1)) while (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ti) __builtin_amdgcn_s_sleep(2);
         asm volatile("" ::: "memory");
         const int rank = state_rank(st);
@@ -191,6 +217,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         }
         wave_lds_sync();
         if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pend = true; q_t = t; q_l0 = l0; q_nl = nl;
     }
     __syncthreads();
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
@@ -290,7 +317,7 @@ inline int fused_upload(FusedPlan &pl, T **dst, const T *src, size_t n, hipStrea
 inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
 {
     const int acc_doubles = p.C * 27;
-    const size_t shmem = sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * WAVE_LDS_DOUBLES + 2);
+    const size_t shmem = sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES) + 2);
     if (shmem > (size_t)LDS_BYTES || p.F == 0 || p.C == 0 || p.T == 0) return 0;      // general sweep instead
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     std::vector<int32_t> blk((size_t)pl.n_blocks + 1);

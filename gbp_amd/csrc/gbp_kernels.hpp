@@ -141,14 +141,15 @@ GBP_DEV void factor_linearise(const Params &p, const double (&x0)[9], const doub
 
 // One factor's sweep in registers (gbp.py:82-84, 64-80, 46-54, 334-373).
 //   in : x0, z, state, adaptive variance, means of the two beliefs,
-//        ceC = eta_C - e_C(old), clC = Lambda_C,  ceL = eta_L - e_L(old), clL = Lambda_L   (cl* are consumed),
+//        ceC = eta_C - e_C(old), clC = Lambda_C,  lmk_belief_eta(out[3]) yields eta_L when it is needed, clL = Lambda_L
+//        (cl* are consumed),
 //        old message etas eC / eL and old cores WC / VL
 //   out: new eC / eL / WC / VL (both messages from the OLD ones, gbp.py:371-373), dense new Lambda MCn / MLn for the
 //        belief sums, x0 / state / avar updated; returns true when the factor relinearised (x0 changed).
-template <int LOSS>
+template <int LOSS, typename LmkEta>
 GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
                          const double (&muC)[6], const double (&muL)[3],
-                         const double (&ceC)[6], double (&clC)[21], const double (&ceL)[3], double (&clL)[6],
+                         const double (&ceC)[6], double (&clC)[21], LmkEta &&lmk_belief_eta, double (&clL)[6],
                          double (&eC)[6], double (&eL)[3], double (&WC)[3], double (&VL)[3],
                          double (&MCn)[21], double (&MLn)[6])
 {
@@ -168,6 +169,10 @@ GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2],
     }
     double eLn[3];
     message_to_landmark_cavity(L, ceC, clC, eL, eLn, MLn, VL);
+    double ceL[3];                                         // fetched only now: three doubles less through the 6x6 elimination
+    lmk_belief_eta(ceL);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ceL[i] -= eL[i];
     message_to_camera_cavity(L, ceL, clL, eC, MCn, WC);
 #pragma unroll
     for (int i = 0; i < 3; ++i) eL[i] = eLn[i];
@@ -227,11 +232,9 @@ __global__ __launch_bounds__(BLOCK, GBP_KF_WAVES) void k_factor(Params p)
     for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
     int st = p.state[slot];
     double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
-    double etaC[6], lamC[21], muC[6], ceL[3], lamL[6], muL[3];
+    double etaC[6], lamC[21], muC[6], lamL[6], muL[3];
     load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, lamC, muC);
     const double *lr = p.lrec + (size_t)lmk * LREC;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ceL[k] = lr[LR_BEL + k] - eL[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
 #pragma unroll
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(BLOCK, GBP_KF_WAVES) void k_factor(Params p)
     for (int k = 0; k < 6; ++k) etaC[k] -= eC[k];
 
     double MCn[21], MLn[6];
-    const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC, ceL, lamL, eC, eL, WC, VL, MCn, MLn);
+    const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC,
+                                         [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
+                                         lamL, eC, eL, WC, VL, MCn, MLn);
 
     if (relin) {
 #pragma unroll
