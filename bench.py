@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--cams', type=int, default=500)
     ap.add_argument('--lmks', type=int, default=100_000)
     ap.add_argument('--obs', type=int, default=10)
+    ap.add_argument('--bal', default=None, help='BAL text file instead of the synthetic graph (BASELINE configs 2-3, e.g. '
+                                                'tests/golden/data/fr1desk.txt); not the headline workload')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -105,8 +107,14 @@ def main():
         raise SystemExit("bench.py needs a MI355X: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
 
-    from gbp_amd.synthetic import make_synthetic
-    problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0)
+    if args.bal:
+        from gbp_amd.balio import read_bal
+        problem = read_bal(args.bal)
+        workload = f"BAL file {os.path.basename(args.bal)}"
+    else:
+        from gbp_amd.synthetic import make_synthetic
+        problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0)
+        workload = "synthetic BAL"
     F, L, C = problem.n_factors, problem.n_lmks, problem.n_cams
 
     if world > 1:
@@ -155,12 +163,12 @@ def main():
         k_avg_ms = k_ms / max(k_n, 1)
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_n else 0.0
         out = {
-            "metric": "GBP iterations/sec (whole node), 1M-factor BA graph",
+            "metric": "GBP iterations/sec (whole node), 1M-factor BA graph" if F == 1_000_000 else f"GBP iterations/sec, {F}-factor BA graph",
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic BAL {C} cams x {L} landmarks x {F} reprojection factors "
-                                   f"(gbp_amd.synthetic.make_synthetic seed 0), ba.py defaults, loss=None",
+            "config": {"workload": f"{workload} {C} cams x {L} landmarks x {F} reprojection factors "
+                                   + ("" if args.bal else "(gbp_amd.synthetic.make_synthetic seed 0), ") + "ba.py defaults, loss=None",
                        "n_cams": C, "n_lmks": L, "n_factors": F,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
                        "sweep": "fused" if info['fused'] else "general"},

@@ -65,6 +65,9 @@ SIGNATURES = {
     'gbp_ba_shard_end': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32]),
     'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_get_kernel_timing': (ct.c_int, [ct.c_void_p, _dp, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_char_p)]),
+    'gbp_ba_state_size': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_uint64)]),
+    'gbp_ba_save_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
+    'gbp_ba_load_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
     'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
 }
 

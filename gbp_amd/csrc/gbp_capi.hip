@@ -796,6 +796,103 @@ int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
     return GBP_OK;
 }
 
+// ------------------------------------------------------------------------ state checkpoint ---
+// SURVEY.md 8f rank 4 (the reference keeps its state in Python objects and has no counterpart).  The blob is everything a
+// sweep reads or writes -- linearisation points and adaptive variances, both messages, the relinearisation state words,
+// beliefs, means and priors -- in the engine's internal order, behind a header that pins the graph it belongs to.
+
+namespace {
+struct StateHeader {
+    char magic[8];                 // "GBPSTATE"
+    uint32_t version, has_beliefs;
+    int32_t F, T, L, C;
+    uint64_t graph_hash;           // FNV-1a over the factor -> (slot, camera, landmark) maps
+    uint64_t payload_bytes;
+};
+
+uint64_t fnv1a(uint64_t hsh, const void *data, size_t n)
+{
+    const unsigned char *b = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) { hsh ^= b[i]; hsh *= 1099511628211ull; }
+    return hsh;
+}
+
+uint64_t graph_hash(const gbp_ba *h)
+{
+    uint64_t v = 1469598103934665603ull;
+    v = fnv1a(v, h->ref2slot.data(), h->ref2slot.size() * sizeof(int32_t));
+    v = fnv1a(v, h->ref_cam.data(), h->ref_cam.size() * sizeof(int32_t));
+    v = fnv1a(v, h->ref_lmk.data(), h->ref_lmk.size() * sizeof(int32_t));
+    return v;
+}
+
+struct StatePart { void *dev; size_t bytes; };
+
+std::vector<StatePart> state_parts(gbp_ba *h)
+{
+    const Params &p = h->p;
+    const size_t S = (size_t)p.T * WTILE;
+    return {{p.lin, S * LIN_ROWS * sizeof(double)}, {p.msg, S * MSG_ROWS * sizeof(double)}, {p.state, S * sizeof(int)},
+            {p.lrec, (size_t)p.L * LREC * sizeof(double)}, {p.cbel, (size_t)p.C * CAMREC * sizeof(double)},
+            {p.cprior, (size_t)p.C * 27 * sizeof(double)}};
+}
+}  // namespace
+
+int gbp_ba_state_size(gbp_ba_t *h, uint64_t *bytes)
+{
+    ENTER(h);
+    if (!bytes) return fail(GBP_EINVAL, "bytes is NULL");
+    uint64_t n = sizeof(StateHeader);
+    for (const StatePart &q : state_parts(h)) n += q.bytes;
+    *bytes = n;
+    return GBP_OK;
+}
+
+int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
+{
+    ENTER(h);
+    uint64_t need = 0;
+    CHK(gbp_ba_state_size(h, &need));
+    if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
+    StateHeader hd{};
+    std::memcpy(hd.magic, "GBPSTATE", 8);
+    hd.version = 1; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
+    hd.graph_hash = graph_hash(h);
+    hd.payload_bytes = need - sizeof(StateHeader);
+    char *out = static_cast<char *>(buf);
+    std::memcpy(out, &hd, sizeof hd);
+    out += sizeof hd;
+    for (const StatePart &q : state_parts(h)) {
+        if (q.bytes) HIPCHK(hipMemcpyAsync(out, q.dev, q.bytes, hipMemcpyDeviceToHost, h->stream));
+        out += q.bytes;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GBP_OK;
+}
+
+int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
+{
+    ENTER(h);
+    uint64_t need = 0;
+    CHK(gbp_ba_state_size(h, &need));
+    if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
+    StateHeader hd;
+    std::memcpy(&hd, buf, sizeof hd);
+    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 1) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
+    if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != graph_hash(h))
+        return fail(GBP_EINVAL, "state blob belongs to a different graph (F/L/C or factor order differ)");
+    if (bytes < need || hd.payload_bytes != need - sizeof(StateHeader)) return fail(GBP_EINVAL, "state blob truncated");
+    const char *in = static_cast<const char *>(buf) + sizeof hd;
+    for (const StatePart &q : state_parts(h)) {
+        if (q.bytes) HIPCHK(hipMemcpyAsync(q.dev, in, q.bytes, hipMemcpyHostToDevice, h->stream));
+        in += q.bytes;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->has_beliefs = hd.has_beliefs != 0;
+    return GBP_OK;
+}
+
 // ------------------------------------------------------------------------ instrumentation ---
 
 int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable)

@@ -185,6 +185,25 @@ class BAEngine:
             check(self._lib.gbp_ba_set_iters_since_relin(self._h, iptr(a)))
 
     # ---- instrumentation -------------------------------------------------------------------
+    # ---- checkpoint / restore (include/gbp_ba.h: gbp_ba_save_state) --------------------------------
+    def save_state(self):
+        """Everything a sweep reads or writes, as one uint8 array (restores only into an engine of the same graph)."""
+        n = ct.c_uint64()
+        check(self._lib.gbp_ba_state_size(self._h, ct.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        check(self._lib.gbp_ba_save_state(self._h, buf.ctypes.data_as(ct.c_void_p), n))
+        return buf
+
+    def load_state(self, blob):
+        buf = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self._lib.gbp_ba_load_state(self._h, buf.ctypes.data_as(ct.c_void_p), ct.c_uint64(buf.size)))
+
+    def save(self, path):
+        np.save(path, self.save_state(), allow_pickle=False)
+
+    def load(self, path):
+        self.load_state(np.load(path, allow_pickle=False))
+
     def set_kernel_timing(self, on):
         check(self._lib.gbp_ba_set_kernel_timing(self._h, int(bool(on))))
 

@@ -116,6 +116,14 @@ int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, in
 int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks);
 #define GBP_CAM_PARTIAL_DOUBLES 27
 
+/* state checkpoint / restore (the reference holds its state in Python objects and has no
+ * counterpart).  The blob holds everything a sweep reads or writes (linearisation points, adaptive variances, messages,
+ * relinearisation state, beliefs, means, priors) behind a header that pins the graph; it restores only into a handle
+ * created from the same graph.  A restored handle continues bit-identically. */
+int gbp_ba_state_size(gbp_ba_t *h, uint64_t *bytes);
+int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes);
+int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes);
+
 /* instrumentation for bench.py: HIP-event time of the dominant (factor) kernel on the handle's stream */
 int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
 int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);

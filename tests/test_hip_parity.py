@@ -323,3 +323,37 @@ def test_sharded_driver_single_rank_nccl(eng_mod, oracle_mod):
         assert g.are() == pytest.approx(e.are(), rel=1e-12)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_checkpoint_restore_continues_bit_identically(eng_mod, fused, tmp_path):
+    """gbp_ba_save_state / gbp_ba_load_state: a restored engine -- the same handle or a fresh one
+    of the same graph -- repeats the following sweeps bit for bit, across a relinearisation (sweeps 9..16 of the ba.py
+    schedule); a blob of a different graph is refused."""
+    p, e = make(eng_mod, 'fr1desk_vsmall.txt', fused=fused)
+    e.set_iters_since_relin(1)
+    e.iterate(6)
+    blob = e.save_state()
+    e.iterate(12)
+    want_b, want_m, want_s = e.beliefs(), e.messages(), e.relin_state()
+    e.load_state(blob)
+    e.iterate(12)
+    for a, b in zip(e.beliefs(), want_b):
+        assert np.array_equal(a, b)
+    fresh = eng_mod.BAEngine.from_problem(p, fused=fused)
+    path = os.path.join(tmp_path, 'state.npy')
+    np.save(path, blob)
+    fresh.load(path)
+    fresh.iterate(12)
+    for a, b in zip(fresh.beliefs(), want_b):
+        assert np.array_equal(a, b)
+    got_m, got_s = fresh.messages(), fresh.relin_state()
+    for a, b in zip(got_m, want_m):
+        assert np.array_equal(a, b)
+    for k in want_s:
+        assert np.array_equal(got_s[k], want_s[k]), k
+    _, other = make(eng_mod, 'fr1desk_small.txt', fused=fused)
+    with pytest.raises(Exception):
+        other.load_state(blob)
+    with pytest.raises(Exception):
+        e.load_state(blob[:100])
