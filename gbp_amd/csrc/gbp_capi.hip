@@ -7,6 +7,7 @@
 #include "../../include/gbp_ba.h"
 #include "gbp_kernels.hpp"
 #include "gbp_fused.hpp"
+#include "gbp_balio.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -793,6 +794,34 @@ int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
     const int n = h->p.T * WTILE;
     if (n) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p.state, n, value);
     HIPCHK(hipGetLastError());
+    return GBP_OK;
+}
+
+// ------------------------------------------------------------------------------ BAL files ---
+// utils/read_balfile.py:4-37 (called from create_ba_graph gbp_ba.py:108-109); host only.
+
+int gbp_bal_header(const char *path, int32_t *n_cams, int32_t *n_lmks, int32_t *n_obs)
+{
+    if (!path || !n_cams || !n_lmks || !n_obs) return fail(GBP_EINVAL, "NULL argument");
+    BalText t;
+    std::string err;
+    long C, L, F;
+    if (t.open(path, err) || bal_header(t, C, L, F, err)) return fail(GBP_EINVAL, "%s: %s", path, err.c_str());
+    if (C > INT32_MAX || L > INT32_MAX || F > INT32_MAX) return fail(GBP_EINVAL, "%s: sizes exceed int32", path);
+    *n_cams = (int32_t)C; *n_lmks = (int32_t)L; *n_obs = (int32_t)F;
+    return GBP_OK;
+}
+
+int gbp_bal_read(const char *path, int32_t n_cams, int32_t n_lmks, int32_t n_obs, double *K4, double *cam_means,
+                 double *lmk_means, double *meas, int32_t *cam_idx, int32_t *lmk_idx)
+{
+    if (!path || !K4 || !cam_means || !lmk_means || !meas || !cam_idx || !lmk_idx) return fail(GBP_EINVAL, "NULL argument");
+    BalText t;
+    std::string err;
+    long C, L, F;
+    if (t.open(path, err) || bal_header(t, C, L, F, err)) return fail(GBP_EINVAL, "%s: %s", path, err.c_str());
+    if (C != n_cams || L != n_lmks || F != n_obs) return fail(GBP_EINVAL, "%s: sizes differ from gbp_bal_header's", path);
+    if (bal_body(t, C, L, F, K4, cam_means, lmk_means, meas, cam_idx, lmk_idx, err)) return fail(GBP_EINVAL, "%s: %s", path, err.c_str());
     return GBP_OK;
 }
 

@@ -116,6 +116,13 @@ int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, in
 int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks);
 #define GBP_CAM_PARTIAL_DOUBLES 27
 
+/* BAL-style text files (layout data/README.md:5-14), host only: replaces utils/read_balfile.py:4-37.  First the sizes,
+ * then the arrays into caller-owned buffers: K4 = fx fy cx cy, cam_means[C*6], lmk_means[L*3], meas[F*2], ids[F] in FILE
+ * order (gbp_ba_create takes them in this order and applies the reference's camera-major factor order itself). */
+int gbp_bal_header(const char *path, int32_t *n_cams, int32_t *n_lmks, int32_t *n_obs);
+int gbp_bal_read(const char *path, int32_t n_cams, int32_t n_lmks, int32_t n_obs, double *K4, double *cam_means,
+                 double *lmk_means, double *meas, int32_t *cam_idx, int32_t *lmk_idx);
+
 /* state checkpoint / restore (the reference holds its state in Python objects and has no
  * counterpart).  The blob holds everything a sweep reads or writes (linearisation points, adaptive variances, messages,
  * relinearisation state, beliefs, means, priors) behind a header that pins the graph; it restores only into a handle

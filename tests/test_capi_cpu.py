@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import REPO
+from conftest import DATA, REPO
 
 
 @pytest.fixture(scope='module')
@@ -66,3 +66,31 @@ def test_bad_arguments_are_reported_not_crashed(capi):
     assert lib.gbp_ba_create(ct.byref(h), ct.byref(d)) == -1
     assert b'negative' in lib.gbp_last_error()
     assert lib.gbp_ba_iterate(None, 1, 1, 1) == -1
+
+
+def test_native_bal_reader_equals_python_reader(tmp_path):
+    """gbp_bal_header / gbp_bal_read (host-only C++) against the Python restatement of utils/read_balfile.py:4-37:
+    identical arrays on every data file of the reference and on a generated file; malformed files are refused."""
+    import glob
+    from gbp_amd import _capi
+    from gbp_amd.balio import read_bal, read_bal_native
+    from gbp_amd.synthetic import make_synthetic, write_bal
+    _capi.load()
+    files = sorted(glob.glob(os.path.join(DATA, '*.txt')))
+    assert files
+    syn = os.path.join(tmp_path, 'syn.txt')
+    write_bal(make_synthetic(n_cams=12, n_lmks=300, obs_per_lmk=5, seed=3), syn)
+    for f in files + [syn]:
+        a, b = read_bal(f, native=False), read_bal_native(f)
+        for k in ('K', 'cam_means', 'lmk_means', 'meas', 'cam_idx', 'lmk_idx'):
+            x, y = getattr(a, k), getattr(b, k)
+            assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y), (f, k)
+    bad = os.path.join(tmp_path, 'bad.txt')
+    with open(syn) as fh:
+        lines = fh.read().split('\n')
+    with open(bad, 'w') as fh:
+        fh.write('\n'.join(lines[:40]))                       # truncated
+    with pytest.raises(_capi.GbpError):
+        read_bal_native(bad)
+    with pytest.raises(_capi.GbpError):
+        read_bal_native(os.path.join(tmp_path, 'missing.txt'))
