@@ -70,8 +70,26 @@ SIGNATURES = {
     'gbp_ba_state_size': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_uint64)]),
     'gbp_ba_save_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
     'gbp_ba_load_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
+    'gbp_lin_create': (ct.c_int, [ct.POINTER(ct.c_void_p), ct.c_void_p]),
+    'gbp_lin_destroy': (None, [ct.c_void_p]),
+    'gbp_lin_sync': (ct.c_int, [ct.c_void_p]),
+    'gbp_lin_update_beliefs': (ct.c_int, [ct.c_void_p]),
+    'gbp_lin_iterate': (ct.c_int, [ct.c_void_p, ct.c_int32]),
+    'gbp_lin_energy': (ct.c_int, [ct.c_void_p, _dp]),
+    'gbp_lin_get_beliefs': (ct.c_int, [ct.c_void_p, _dp, _dp]),
+    'gbp_lin_get_means': (ct.c_int, [ct.c_void_p, _dp]),
+    'gbp_lin_get_messages': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
     'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
 }
+
+
+
+class LinDesc(ct.Structure):
+    """gbp_lin_desc_t (include/gbp_lin.h)."""
+    _fields_ = [('n_vars', ct.c_int32), ('dofs', ct.c_int32), ('n_factors', ct.c_int32), ('device', ct.c_int32),
+                ('var_a', _ip), ('var_b', _ip), ('factor_eta', _dp), ('factor_lam', _dp), ('factor_const', _dp),
+                ('prior_eta', _dp), ('prior_lam', _dp), ('eta_damping', ct.c_double)]
+
 
 _lib = None
 

@@ -33,6 +33,20 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+namespace gbp {
+// shared with gbp_lin_capi.hip
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace gbp
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e__ = (expr);                                                                       \
@@ -830,6 +844,7 @@ int gbp_bal_read(const char *path, int32_t n_cams, int32_t n_lmks, int32_t n_obs
 // sweep reads or writes -- linearisation points and adaptive variances, both messages, the relinearisation state words,
 // beliefs, means and priors -- in the engine's internal order, behind a header that pins the graph it belongs to.
 
+extern "C++" {
 namespace {
 struct StateHeader {
     char magic[8];                 // "GBPSTATE"
@@ -866,6 +881,7 @@ std::vector<StatePart> state_parts(gbp_ba *h)
             {p.cprior, (size_t)p.C * 27 * sizeof(double)}};
 }
 }  // namespace
+}  // extern "C++"
 
 int gbp_ba_state_size(gbp_ba_t *h, uint64_t *bytes)
 {

@@ -18,17 +18,20 @@ def capi():
 
 
 def declared_symbols():
-    text = open(os.path.join(REPO, 'include', 'gbp_ba.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(gbp_[a-z_0-9]+)\s*\(', text)))
+    import glob
+    names = set()
+    for h in glob.glob(os.path.join(REPO, 'include', '*.h')):
+        text = re.sub(r'/\*.*?\*/', '', open(h).read(), flags=re.S)
+        names |= set(re.findall(r'\b(gbp_[a-z_0-9]+)\s*\(', text))
+    return sorted(names)
 
 
 def test_header_symbols_all_exported_and_bound(capi):
     lib = capi.load()
     names = declared_symbols()
-    assert len(names) >= 25
+    assert len(names) >= 40
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/gbp_ba.h but not exported by libgbp_hip.so"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported by libgbp_hip.so"
     assert set(names) == set(capi.SIGNATURES), set(names) ^ set(capi.SIGNATURES)
     assert lib.gbp_abi_version() == 1
 
