@@ -357,3 +357,62 @@ def test_checkpoint_restore_continues_bit_identically(eng_mod, fused, tmp_path):
         other.load_state(blob)
     with pytest.raises(Exception):
         e.load_state(blob[:100])
+
+
+def test_full_size_properties_1m_factors(eng_mod):
+    """BASELINE configs[3] (500 cams x 100k landmarks x 1M factors) is too big for the CPU oracle in a test, so the
+    full-size run is checked through properties that do not depend on size:
+      * the fused sweep is bitwise reproducible run to run (fixed summation order);
+      * the fused and the general sweep agree (two independent implementations of the same maths);
+      * belief = prior + sum of incoming messages, per variable, from the exported messages (a checksum over all 2M edges);
+      * relabelling the landmarks (and thereby moving every factor to another tile / workgroup) leaves camera beliefs
+        unchanged and permutes landmark beliefs;
+      * the energy of the converging run decreases over the first sweeps."""
+    p = make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0)
+    assert p.n_factors == 1_000_000
+
+    def run(problem, fused, n=6):
+        e = eng_mod.BAEngine.from_problem(problem, fused=fused)
+        e.generate_priors_var(50.0)
+        e.update_all_beliefs()
+        en = [e.energy()]
+        for _ in range(n):
+            e.iterate(1)
+            en.append(e.energy())
+        return e, en
+
+    e1, en1 = run(p, True)
+    b1 = e1.beliefs()
+    assert e1.info()['fused']
+    e2, _ = run(p, True)
+    for a, b in zip(b1, e2.beliefs()):
+        assert np.array_equal(a, b)                                   # bitwise
+    e2.close()
+    eg, _ = run(p, False)
+    assert max(rel_err_rows(a, b) for a, b in zip(b1, eg.beliefs())) < 1e-9
+    eg.close()
+    assert en1[-1] < en1[1] < en1[0]
+
+    # checksum over all edges
+    ce, cl, le, ll = b1
+    pce, pcl, ple, pll = e1.priors()
+    mce, mcl, mle, mll = e1.messages()
+    fac = e1.factors(dense=False)
+    s_ce, s_cl = pce.copy(), pcl.copy()
+    np.add.at(s_ce, fac['cam'], mce); np.add.at(s_cl, fac['cam'], mcl)
+    s_le, s_ll = ple.copy(), pll.copy()
+    np.add.at(s_le, fac['lmk'], mle); np.add.at(s_ll, fac['lmk'], mll)
+    assert rel_err_rows(s_ce, ce) < 1e-10 and rel_err_rows(s_cl, cl) < 1e-10
+    assert rel_err_rows(s_le, le) < 1e-10 and rel_err_rows(s_ll, ll) < 1e-10
+    del mce, mcl, mle, mll
+
+    # landmark relabelling
+    perm = np.random.default_rng(5).permutation(p.n_lmks)              # new id of landmark l = perm[l]
+    inv = np.empty_like(perm); inv[perm] = np.arange(p.n_lmks)
+    q = BAProblem(K=p.K, cam_means=p.cam_means, lmk_means=p.lmk_means[inv], meas=p.meas, cam_idx=p.cam_idx,
+                  lmk_idx=perm[p.lmk_idx].astype(np.int32))
+    e3, _ = run(q, True)
+    ce3, cl3, le3, ll3 = e3.beliefs()
+    assert rel_err_rows(ce3, ce) < 1e-9 and rel_err_rows(cl3, cl) < 1e-9
+    assert rel_err_rows(le3[perm], le) < 1e-9 and rel_err_rows(ll3[perm], ll) < 1e-9
+    e3.close(); e1.close()
