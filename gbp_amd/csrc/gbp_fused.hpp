@@ -227,46 +227,44 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     }
 }
 
-// One workgroup per camera: partial[c] = sum over the per-workgroup tables (fixed tree -> bitwise reproducible).  With
-// finish != 0 (single GPU: nothing to exchange) the camera belief is completed in place: prior + sum, 6x6 solve
-// (VariableNode.update_belief gbp.py:182-193), which saves a dependent launch.
+// One workgroup per camera: partial[c] = sum over the per-workgroup tables in a fixed order (bitwise reproducible).
+// The camera's n_blocks x 27 run is copied to LDS with fully coalesced 16-byte loads (a lane-per-table read touches 64
+// different lines per instruction and was TA-bound: 12.4 us); then 9 x 27 threads add every 9th table and 27 threads add
+// the nine partial sums.  With finish != 0 (single GPU: nothing to exchange) the camera belief is completed in place:
+// prior + sum, 6x6 solve (VariableNode.update_belief gbp.py:182-193), which saves a dependent launch.
+constexpr int RED_PARTS = 9;
 __global__ __launch_bounds__(BLOCK) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
                                                            double *__restrict__ partial, int finish)
 {
-    __shared__ double red[BLOCK / 64][27];
-    __shared__ double tot[27];
-    const int c = blockIdx.x;
-    double acc[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
-        const double *src = block_partials + ((size_t)c * n_blocks + b) * 27;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] += src[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        acc[k] = v;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) red[wave][k] = acc[k];
+    extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][27] | red[RED_PARTS][27] | tot[27]
+    const int c = blockIdx.x, n = n_blocks * 27, tid = threadIdx.x;
+    double *red = sh + ((n + 1) & ~1), *tot = red + RED_PARTS * 27;
+    const double *src = block_partials + (size_t)c * n;
+    if (((size_t)c * n & 1) == 0) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+        for (int i = tid; i < n / 2; i += BLOCK) { const double2 v = s2[i]; sh[2 * i] = v.x; sh[2 * i + 1] = v.y; }
+        if ((n & 1) && tid == 0) sh[n - 1] = src[n - 1];
+    } else {
+        for (int i = tid; i < n; i += BLOCK) sh[i] = src[i];
     }
     __syncthreads();
-    if (threadIdx.x < 27) {
-        double s = red[0][threadIdx.x];
+    if (tid < RED_PARTS * 27) {
+        const int part = tid / 27, k = tid - part * 27;
+        double s = 0.0;
+        for (int b = part; b < n_blocks; b += RED_PARTS) s += sh[b * 27 + k];
+        red[part * 27 + k] = s;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        double s = red[tid];
 #pragma unroll
-        for (int w = 1; w < BLOCK / 64; ++w) s += red[w][threadIdx.x];
-        partial[(size_t)c * 27 + threadIdx.x] = s;
-        tot[threadIdx.x] = s + p.cprior[(size_t)c * 27 + threadIdx.x];
+        for (int q = 1; q < RED_PARTS; ++q) s += red[q * 27 + tid];
+        partial[(size_t)c * 27 + tid] = s;
+        tot[tid] = s + p.cprior[(size_t)c * 27 + tid];
     }
     if (!finish) return;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double *rec = p.cbel + (size_t)c * CAMREC;
         double eta[6], lam[21], mu[6];
 #pragma unroll
@@ -336,6 +334,8 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
                             (int)shmem) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
 #undef GBP_SET_SHMEM
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
     pl.enabled = true;
     return 0;
 }
@@ -355,7 +355,8 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     }
     if (e1) (void)hipEventRecord(e1, stream);
     if (pl.n_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
-    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(BLOCK), 0, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);
+    const size_t red_shmem = sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27);
+    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(BLOCK), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);
     return (int)hipGetLastError();
 }
 
