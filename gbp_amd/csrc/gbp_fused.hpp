@@ -9,10 +9,13 @@
 //     (prior + sum in adj_factors order, gbp.py:182-188) are formed by the same wave;
 //   * camera messages are accumulated into a per-workgroup LDS table acc[C][27] (500 cameras = 108 KB of
 //     the CU's 160 KB).  One workgroup per CU walks a fixed contiguous range of tiles and stores its table
-//     at the end; k_cam_reduce_blocks sums the per-workgroup tables in workgroup order;
+//     at the end ([camera][workgroup][27]); k_cam_reduce_tree sums the tables per camera in a fixed order and,
+//     on a single GPU, finishes the camera belief (prior + sum, 6x6 solve) in the same launch;
 //   * the 8 waves of a workgroup are autonomous: each pulls the next tile of the workgroup's range from an
 //     LDS counter and never meets the others at an s_barrier, so while one wave waits for HBM another does
 //     fp64 maths on the same SIMD (two waves per SIMD, 256 VGPRs each);
+//   * the landmark-belief phase of a tile is pure LDS work; it runs one iteration LATE, after the next tile's
+//     loads have been issued, so the wave keeps HBM requests in flight (139 -> 116 us per sweep at 1M factors);
 //   * determinism without barriers: a wave may add its tile's camera messages to acc only when all earlier
 //     tiles of the workgroup have done so (LDS ticket `done`), and lanes of one tile that hit the same camera
 //     add in the order of a pre-computed rank (kept in the state word).  The summation order is therefore
@@ -20,12 +23,12 @@
 //     every lane targets a different camera, so the LDS ds_add_f64 is a plain read-modify-write.
 //
 // HBM traffic per sweep: F*(26 read + 15 written doubles + 12 B of indices) + L*(24 read + 12 written doubles)
-// + the workgroup tables (256 * C * 27 doubles written and read once) -- a third of the "algorithmic" 1072 B per
-// factor of SURVEY.md 8d, which assumed dense message precisions and a second pass over the messages.
+// + the workgroup tables (256 * C * 27 doubles written and read once) -- well under half of the "algorithmic"
+// 1072 B per factor of SURVEY.md 8d, which assumed dense message precisions and a second pass over the messages.
 //
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
-// and their beliefs are formed afterwards by k_lmk_belief_list.  If acc does not fit the LDS (C > ~540) the
-// plan stays disabled and the general sweep runs.
+// and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
+// (C > 516) the plan stays disabled and the general sweep runs.
 #pragma once
 #include "gbp_kernels.hpp"
 #include <cstdint>
