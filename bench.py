@@ -158,8 +158,8 @@ def main():
         L_local = graph.L
         if k_name == 'k_sweep_fused':
             bytes_per_launch = algorithmic_bytes(F_local, L_local, C)
-        else:                               # k_factor: factor stage only (62 doubles read + 36 written per factor)
-            bytes_per_launch = F_local * 98 * 8
+        else:                               # k_factor_tile: factor stage (62 doubles read + 36 written per factor) + landmark beliefs
+            bytes_per_launch = F_local * (98 + 9) * 8 + L_local * 168
         k_avg_ms = k_ms / max(k_n, 1)
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9 if k_n else 0.0
         out = {

@@ -69,6 +69,7 @@ struct gbp_ba {
     std::vector<int32_t> h_cptr;                 // camera CSR offsets in reference order
     std::vector<int32_t> h_lrow0, h_lrow1;       // per landmark: its slot range [row0, row1)
     std::vector<int32_t> big_lmks;               // landmarks larger than a tile
+    int *d_big = nullptr;                        // the same on the device (general sweep)
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -82,7 +83,7 @@ struct gbp_ba {
     bool timing = false;
     std::vector<hipEvent_t> ev;                  // pairs
     size_t ev_used = 0;
-    const char *dominant = "k_factor";
+    const char *dominant = "k_factor_tile";
 };
 
 template <typename T>
@@ -152,12 +153,12 @@ static int launch_factor_stage(gbp_ba *h, int robustify, int local_relin)
     Params p = h->p;
     p.robustify = robustify; p.local_relin = local_relin;
     if (!p.T) return GBP_OK;
-    const int nb = grid_for((size_t)p.T * WTILE);
+    const int nb = (p.T + BLOCK / 64 - 1) / (BLOCK / 64);
     CHK(time_begin(h));
     switch (p.loss) {
-    case GBP_LOSS_NONE: hipLaunchKernelGGL(k_factor<0>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
-    case GBP_LOSS_HUBER: hipLaunchKernelGGL(k_factor<1>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
-    default: hipLaunchKernelGGL(k_factor<2>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+    case GBP_LOSS_NONE: hipLaunchKernelGGL(k_factor_tile<0>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+    case GBP_LOSS_HUBER: hipLaunchKernelGGL(k_factor_tile<1>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+    default: hipLaunchKernelGGL(k_factor_tile<2>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
     }
     CHK(time_end(h));
     HIPCHK(hipGetLastError());
@@ -188,6 +189,25 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
     return GBP_OK;
 }
 
+// camera-major staging of the general sweep, allocated on first use (F x 27 doubles + F ints)
+static int ensure_staging(gbp_ba *h)
+{
+    if (h->p.cstage) return GBP_OK;
+    const size_t S = (size_t)h->p.T * WTILE;
+    std::vector<int32_t> cpos(std::max<size_t>(S, 1), 0);
+    for (size_t e = 0; e < h->ref2slot.size(); ++e) cpos[(size_t)h->ref2slot[e]] = (int32_t)e;     // cadj[e] = slot  <=>  cpos[slot] = e
+    int *d_cpos = nullptr;
+    CHK(dev_alloc(h, &d_cpos, cpos.size(), false));
+    CHK(upload(h, d_cpos, cpos));
+    CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * CSTAGE_ROW));
+    if (!h->big_lmks.empty() && !h->d_big) {
+        CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
+        CHK(upload(h, h->d_big, h->big_lmks));
+    }
+    h->p.cpos = d_cpos;
+    return GBP_OK;
+}
+
 // one synchronous_iteration's device work up to (and including) this rank's camera partial sums; with finish != 0 the
 // camera beliefs are completed as well (single GPU) and *finished tells the caller so
 static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish = 0,
@@ -207,8 +227,20 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         if (finished) *finished = finish != 0;
         return GBP_OK;
     }
-    if (with_messages) CHK(launch_factor_stage(h, robustify, local_relin));
-    CHK(launch_lmk_beliefs(h));
+    if (with_messages) {
+        // tile sweep: messages + the tiles' landmark beliefs + camera messages staged camera-major
+        CHK(ensure_staging(h));
+        CHK(launch_factor_stage(h, robustify, local_relin));
+        if (!h->big_lmks.empty()) {
+            hipLaunchKernelGGL(k_lmk_belief_list, dim3(((int)h->big_lmks.size() + 63) / 64), dim3(64), 0, h->stream, h->p, h->d_big,
+                               (int)h->big_lmks.size());
+            HIPCHK(hipGetLastError());
+        }
+        if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(1024), 0, h->stream, h->p, partial);
+        HIPCHK(hipGetLastError());
+        return GBP_OK;
+    }
+    CHK(launch_lmk_beliefs(h));                 // update_all_beliefs: from the stored messages
     CHK(launch_cam_partial(h, partial));
     return GBP_OK;
 }

@@ -28,8 +28,10 @@
 // Cameras:   cbel[C][34] = mu 6 | eta 6 | Lambda 21 | pad (gathered per factor, L2-resident: 500 cams = 136 KB),
 //            cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of each camera's factors (reference order).
 //
-// General sweep (any shape) = k_factor (one lane per slot) -> k_lmk_belief (one lane per landmark) ->
-// k_cam_partial (one workgroup per camera, gather) -> k_cam_finish.  The fused sweep is in gbp_fused.hpp.
+// General sweep (any shape) = k_factor_tile (one wave per tile: messages, the tile's landmark beliefs, camera messages
+// staged in camera-major order) -> k_lmk_belief_list (landmarks larger than a tile) -> k_cam_partial_staged (one
+// workgroup per camera, contiguous run) -> k_cam_finish.  k_lmk_belief / k_cam_partial form beliefs from the STORED
+// messages (update_all_beliefs).  The fused sweep is in gbp_fused.hpp.
 #pragma once
 #include "gbp_math.hpp"
 
@@ -47,9 +49,7 @@ constexpr int CAM_MU = 0, CAM_ETA = 6, CAM_LAM = 12;
 constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (camera in the LOW bits + '& 0xffffff' was
                                    // miscompiled by hipcc 7.2: the mask vanished in front of a v_mad_u64_u32 address multiply)
 constexpr int BLOCK = 256;
-#ifndef GBP_KF_WAVES
-#define GBP_KF_WAVES 1
-#endif
+constexpr int CSTAGE_ROW = 27;     // doubles per row of the camera-major staging buffer
 
 struct Params {
     int F, T, L, C;               // factors, tiles (slots = 64 T), landmarks, cameras
@@ -64,6 +64,8 @@ struct Params {
     double *lrec;
     double *cbel, *cprior;
     const int *cptr, *cadj;
+    double *cstage;               // general sweep: [F][27] camera messages in camera-major (reference) order, or NULL
+    const int *cpos;              // slot -> row of cstage
 };
 
 // element (slot, row) of a tile block: rows are stored in PAIRS, [row/2][lane][row%2], so that a lane owns 16 contiguous
@@ -208,61 +210,6 @@ GBP_DEV bool slot_info(const Params &p, int slot, int &cam, int &lmk)
     return true;
 }
 
-// ------------------------------------------------------------------ general sweep, stage 1 --
-// One lane per slot: the per-factor part of synchronous_iteration; both messages are computed from the OLD
-// messages and committed together (Factor.compute_messages gbp.py:334-373).
-template <int LOSS>
-__global__ __launch_bounds__(BLOCK, GBP_KF_WAVES) void k_factor(Params p)
-{
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot >= p.T * WTILE) return;
-    int cam, lmk;
-    if (!slot_info(p, slot, cam, lmk)) return;
-    double x0[9], z[2], eC[6], eL[3], WC[3], VL[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-    z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
-    int st = p.state[slot];
-    double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
-    double etaC[6], lamC[21], muC[6], lamL[6], muL[3];
-    load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, lamC, muC);
-    const double *lr = p.lrec + (size_t)lmk * LREC;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) etaC[k] -= eC[k];
-
-    double MCn[21], MLn[6];
-    const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC,
-                                         [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
-                                         lamL, eC, eL, WC, VL, MCn, MLn);
-
-    if (relin) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_EL + k)] = eL[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
-    p.state[slot] = st;
-    if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
-}
-
 GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6])
 {
     double x0[9], Jc[2][6], Jl[2][3], h[2], WC[3], VL[3];
@@ -283,6 +230,152 @@ GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (
     for (int k = 0; k < 6; ++k) ML[k] = 0.0;
     rank2_update<6>(MC, Jc[0], Jc[1], WC, 1.0);
     rank2_update<3>(ML, Jl[0], Jl[1], VL, 1.0);
+}
+
+// ------------------------------------------------------------- general sweep, tile version --
+// One WAVE per tile: the per-factor part of synchronous_iteration (both messages computed from the OLD messages and
+// committed together, Factor.compute_messages gbp.py:334-373), plus what the tile structure gives for free when the
+// camera table of the fused sweep does not fit the LDS (C > 516):
+//   * the landmarks a tile owns get their beliefs from the same wave (new messages through LDS, prior + sum in
+//     adj_factors order, 3x3 solve) -- no second pass over the messages (k_lmk_belief re-reads and re-linearises them);
+//   * the dense message to the camera (eta 6 | Lambda 21) is written to cstage[cpos[slot]], i.e. in the camera's own
+//     adj_factors order, so k_cam_partial_staged reads one contiguous run per camera instead of gathering 16-byte
+//     pieces and rebuilding Jacobians (k_cam_partial fetches 562 MB per sweep at 1M factors; this is 216 + 216 MB).
+template <int LOSS>
+__global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
+{
+    __shared__ double wls[BLOCK / 64][WTILE * 27];          // per wave: [64][9] landmark messages, then [64][27] camera messages
+    __shared__ int wps[BLOCK / 64][WTILE];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (BLOCK / 64) + wave;
+    if (t >= p.T) return;                                   // whole wave
+    double *wl = wls[wave];
+    int *wp = wps[wave];
+    const int4 td = p.tiles[t];
+    const int l0 = td.x, nl = td.y, nf = td.z;
+    const bool active = lane < nf;
+    const int slot = t * WTILE + lane;
+    double eCout[6], MCout[21];
+    if (active) {
+        const unsigned meta = p.meta[slot];
+        const int cam = (int)(meta >> META_LMK_BITS), lmk = l0 + (int)(meta & ((1u << META_LMK_BITS) - 1u));
+        double x0[9], z[2], eC[6], eL[3], WC[3], VL[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+        z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+        int st = p.state[slot];
+        double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+        double etaC[6], lamC[21], muC[6], lamL[6], muL[3];
+        load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, lamC, muC);
+        const double *lr = p.lrec + (size_t)lmk * LREC;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) etaC[k] -= eC[k];
+
+        double MCn[21], MLn[6];
+        const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC,
+                                             [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
+                                             lamL, eC, eL, WC, VL, MCn, MLn);
+        if (relin) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p.msg[msg_at(slot, ROW_EL + k)] = eL[k]; wl[lane * 9 + k] = eL[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
+        p.state[slot] = st;
+        if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
+        wp[lane] = p.cpos[slot];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eCout[k] = eC[k];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) MCout[k] = MCn[k];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's LDS writes are done (one wave: no barrier needed)
+    if (lane < nl) {                                        // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks
+        double *lr = p.lrec + (size_t)(l0 + lane) * LREC;
+        double b[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = lr[LR_PRIOR + k];
+        const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
+        for (int r = rows.x - t * WTILE; r < rows.y - t * WTILE; ++r) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) b[k] += wl[r * 9 + k];
+        }
+        double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lr[LR_BEL + k] = b[k];
+        spd_solve<3>(lam, eta, mu);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lr[LR_MU + k] = mu[k];
+    }
+    // camera messages -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction
+    // (27 x 64 eight-byte pieces per tile); transposed, two factors' 216-byte runs go out per instruction
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wl[lane * 27 + k] = eCout[k];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) wl[lane * 27 + 6 + k] = MCout[k];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        // (padding the rows to two whole 128-byte lines did not help: the cost is the scatter itself -- every factor's row
+        //  lands in a different DRAM page -- not partial lines)
+        const int half = lane >= 27 ? 1 : 0, k = lane - 27 * half;
+        if (lane < 54) {
+            for (int f = half; f < nf; f += 2) p.cstage[(size_t)wp[f] * CSTAGE_ROW + k] = wl[f * 27 + k];
+        }
+    }
+}
+
+// One workgroup of 1024 threads per camera: partial[c][27] = sum of its staged messages; 37 x 27 threads stride the
+// camera's contiguous run (every 37th factor each), then 27 threads add the 37 partial sums -- fixed order, bitwise
+// reproducible, and the order inside the camera is the reference's adj_factors order.
+constexpr int STAGE_PARTS = 37;
+__global__ __launch_bounds__(1024) void k_cam_partial_staged(Params p, double *__restrict__ partial)
+{
+    __shared__ double red[STAGE_PARTS * 27];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (tid < STAGE_PARTS * 27) {
+        const int part = tid / 27, k = tid - part * 27;
+        const int e0 = p.cptr[c], e1 = p.cptr[c + 1];
+        double s = 0.0;
+        int e = e0 + part;
+        for (; e + 5 * STAGE_PARTS < e1; e += 6 * STAGE_PARTS) {          // six loads in flight, added in order
+            double v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = p.cstage[(size_t)(e + j * STAGE_PARTS) * CSTAGE_ROW + k];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s += v[j];
+        }
+        for (; e < e1; e += STAGE_PARTS) s += p.cstage[(size_t)e * CSTAGE_ROW + k];
+        red[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        double s = red[tid];
+        for (int q = 1; q < STAGE_PARTS; ++q) s += red[q * 27 + tid];
+        partial[(size_t)c * 27 + tid] = s;
+    }
 }
 
 // ------------------------------------------------------------------ general sweep, stage 2 --
