@@ -65,6 +65,8 @@ SIGNATURES = {
     'gbp_ba_shard_end': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32]),
     'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_get_kernel_timing': (ct.c_int, [ct.c_void_p, _dp, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_char_p)]),
+    'gbp_ba_means_snapshot': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_means_fetch': (ct.c_int, [ct.c_void_p, _dp, _dp, ct.c_int32]),
     'gbp_bal_header': (ct.c_int, [ct.c_char_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     'gbp_bal_read': (ct.c_int, [ct.c_char_p, ct.c_int32, ct.c_int32, ct.c_int32, _dp, _dp, _dp, _dp, _ip, _ip]),
     'gbp_ba_state_size': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_uint64)]),

@@ -77,6 +77,11 @@ struct gbp_ba {
     int *d_ids = nullptr; size_t ids_cap = 0;
     std::vector<void *> allocs;
     bool has_beliefs = false;
+    // streaming means export (viewer): device staging, two pinned host mirrors, a copy stream
+    double *d_mu = nullptr, *h_mu[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_landed[2] = {nullptr, nullptr};
+    long snap_count = 0;
     // fused path
     FusedPlan fused;
     // timing of the dominant kernel
@@ -261,6 +266,9 @@ void gbp_ba_destroy(gbp_ba_t *h)
     if (h->d_tmp) (void)hipFree(h->d_tmp);
     if (h->d_ids) (void)hipFree(h->d_ids);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (int i = 0; i < 2; ++i) { if (h->h_mu[i]) (void)hipHostFree(h->h_mu[i]); if (h->ev_landed[i]) (void)hipEventDestroy(h->ev_landed[i]); }
+    if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     fused_destroy(h->fused);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -840,6 +848,55 @@ int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
     const int n = h->p.T * WTILE;
     if (n) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p.state, n, value);
     HIPCHK(hipGetLastError());
+    return GBP_OK;
+}
+
+// ------------------------------------------------------------------ streaming means export ---
+// the reference's viewer thread reads node.mu of every variable once per frame
+// (vis/ba_vis.py:35-55).  A snapshot is taken in stream order (between two sweeps) and travels to a pinned host mirror
+// on a copy stream, so the sweeps that follow do not wait for PCIe; fetch returns the newest snapshot that has landed.
+
+int gbp_ba_means_snapshot(gbp_ba_t *h)
+{
+    ENTER(h);
+    const Params &p = h->p;
+    const size_t n = (size_t)p.C * 6 + (size_t)p.L * 3;
+    if (!h->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&h->ev_landed[i], hipEventDisableTiming));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_mu[i]), std::max<size_t>(n, 1) * sizeof(double), hipHostMallocDefault));
+        }
+        CHK(dev_alloc(h, &h->d_mu, std::max<size_t>(n, 1), false));
+    }
+    const int b = (int)(h->snap_count & 1);
+    if (h->snap_count >= 1) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_landed[(h->snap_count - 1) & 1], 0));   // d_mu is free again
+    if (n) hipLaunchKernelGGL(k_pack_means, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, h->d_mu);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev_packed, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_packed, 0));
+    if (n) HIPCHK(hipMemcpyAsync(h->h_mu[b], h->d_mu, n * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipEventRecord(h->ev_landed[b], h->copy_stream));
+    h->snap_count++;
+    return GBP_OK;
+}
+
+int gbp_ba_means_fetch(gbp_ba_t *h, double *cam_mu, double *lmk_mu, int32_t wait)
+{
+    ENTER(h);
+    if (h->snap_count == 0) return fail(GBP_ESTATE, "no snapshot taken yet (gbp_ba_means_snapshot)");
+    int b = (int)((h->snap_count - 1) & 1);
+    if (wait) {
+        HIPCHK(hipEventSynchronize(h->ev_landed[b]));
+    } else if (hipEventQuery(h->ev_landed[b]) != hipSuccess) {
+        if (h->snap_count < 2) return fail(GBP_ESTATE, "the first snapshot has not landed yet");
+        b ^= 1;                                            // the one before it has (copies are issued in order)
+        HIPCHK(hipEventSynchronize(h->ev_landed[b]));
+    }
+    const Params &p = h->p;
+    if (cam_mu) std::memcpy(cam_mu, h->h_mu[b], (size_t)p.C * 6 * sizeof(double));
+    if (lmk_mu) std::memcpy(lmk_mu, h->h_mu[b] + (size_t)p.C * 6, (size_t)p.L * 3 * sizeof(double));
     return GBP_OK;
 }
 

@@ -589,6 +589,14 @@ __global__ __launch_bounds__(BLOCK) void k_export_messages(Params p, const int *
 }
 
 // Sigma = Lambda^-1 for the covariance view (VariableNode.Sigma gbp.py:192)
+// mu of every variable, cameras then landmarks, dense: the viewer's per-frame read (vis/ba_vis.py:39-43, 111-114)
+__global__ __launch_bounds__(BLOCK) void k_pack_means(Params p, double *__restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < p.C * 6) out[i] = p.cbel[(size_t)(i / 6) * CAMREC + CAM_MU + i % 6];
+    else if (i < p.C * 6 + p.L * 3) { const int j = i - p.C * 6; out[i] = p.lrec[(size_t)(j / 3) * LREC + LR_MU + j % 3]; }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_covariances(Params p, double *__restrict__ cam_sig, double *__restrict__ lmk_sig)
 {
     const int v = blockIdx.x * BLOCK + threadIdx.x;

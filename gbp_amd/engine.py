@@ -185,6 +185,15 @@ class BAEngine:
             check(self._lib.gbp_ba_set_iters_since_relin(self._h, iptr(a)))
 
     # ---- instrumentation -------------------------------------------------------------------
+    # ---- streaming means for a viewer (include/gbp_ba.h: gbp_ba_means_snapshot) ---------------------
+    def means_snapshot(self):
+        check(self._lib.gbp_ba_means_snapshot(self._h))
+
+    def means_fetch(self, wait=True):
+        cm, lm = np.empty((self.C, 6)), np.empty((self.L, 3))
+        check(self._lib.gbp_ba_means_fetch(self._h, dptr(cm), dptr(lm), int(bool(wait))))
+        return cm, lm
+
     # ---- checkpoint / restore (include/gbp_ba.h: gbp_ba_save_state) --------------------------------
     def save_state(self):
         """Everything a sweep reads or writes, as one uint8 array (restores only into an engine of the same graph)."""

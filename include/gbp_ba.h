@@ -116,6 +116,12 @@ int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, in
 int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks);
 #define GBP_CAM_PARTIAL_DOUBLES 27
 
+/* streaming export of all means for a viewer (the reference's viewer thread reads node.mu of every variable per frame,
+ * vis/ba_vis.py:35-55): snapshot = taken in stream order, copied to a pinned host mirror on a copy stream while the
+ * following sweeps run; fetch = the newest snapshot that has landed (wait != 0: block for the latest one). */
+int gbp_ba_means_snapshot(gbp_ba_t *h);
+int gbp_ba_means_fetch(gbp_ba_t *h, double *cam_mu, double *lmk_mu, int32_t wait);
+
 /* BAL-style text files (layout data/README.md:5-14), host only: replaces utils/read_balfile.py:4-37.  First the sizes,
  * then the arrays into caller-owned buffers: K4 = fx fy cx cy, cam_means[C*6], lmk_means[L*3], meas[F*2], ids[F] in FILE
  * order (gbp_ba_create takes them in this order and applies the reference's camera-major factor order itself). */

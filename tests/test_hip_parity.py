@@ -433,3 +433,26 @@ def test_many_cameras_fall_back_to_the_general_sweep(eng_mod, oracle_mod):
     assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
     for a, b in zip(e.messages(), o.messages()):
         assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < MSG_TOL
+
+
+def test_streaming_means_snapshot(eng_mod):
+    """gbp_ba_means_snapshot / gbp_ba_means_fetch: a snapshot is the means at that point of the stream, whatever is
+    enqueued after it; fetch(wait=False) never returns a torn buffer (it falls back to the previous landed snapshot)."""
+    p, e = make(eng_mod, 'fr1desk_small.txt')
+    with pytest.raises(Exception):
+        e.means_fetch()
+    e.iterate(3)
+    want1 = e.means()
+    e.means_snapshot()
+    e.iterate(5)                                     # enqueued behind the snapshot
+    got1 = e.means_fetch(wait=True)
+    for a, b in zip(got1, want1):
+        assert np.array_equal(a, b)
+    want2 = e.means()
+    e.means_snapshot()
+    e.iterate(2)
+    got = e.means_fetch(wait=False)
+    assert any(np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) for w in (want1, want2))
+    got2 = e.means_fetch(wait=True)
+    for a, b in zip(got2, want2):
+        assert np.array_equal(a, b)
