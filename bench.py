@@ -166,7 +166,7 @@ def main():
             "metric": "GBP iterations/sec (whole node), 1M-factor BA graph" if F == 1_000_000 else f"GBP iterations/sec, {F}-factor BA graph",
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "fixture file (tests/golden/data)" if args.bal else "synthetic",
             "config": {"workload": f"{workload} {C} cams x {L} landmarks x {F} reprojection factors "
                                    + ("" if args.bal else "(gbp_amd.synthetic.make_synthetic seed 0), ") + "ba.py defaults, loss=None",
                        "n_cams": C, "n_lmks": L, "n_factors": F,
