@@ -1,5 +1,4 @@
-from . import lie_algebra
-from . import transformations
-from . import read_balfile
-from . import gaussian
-from . import derivatives
+"""Host-side helpers under the reference's `utils` import names."""
+from . import derivatives, gaussian, lie_algebra, read_balfile, transformations
+
+__all__ = ['derivatives', 'gaussian', 'lie_algebra', 'read_balfile', 'transformations']
