@@ -96,6 +96,30 @@ class LinDesc(ct.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; libgbp_hip.so links the
+    system one, which has the SAME soname, so whichever is mapped first serves both -- and torch cannot initialise on a
+    newer system runtime ("No HIP GPUs are available") when this library happened to be loaded before `import torch`
+    (the sharded driver needs both in one process).  If torch is installed, map ITS runtime first; the kernels here only
+    need the plain HIP API and run on either.  GBP_SYSTEM_HIP=1 keeps the system runtime."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules or os.environ.get('GBP_SYSTEM_HIP'):
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        try:
+            ct.CDLL(path, mode=ct.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libgbp_hip.so and bind every declared symbol (AttributeError if one is missing)."""
     global _lib
@@ -103,6 +127,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m gbp_amd.build` "
                               f"(hipcc --offload-arch=gfx950).  gbp_amd has no CPU fallback.")
+        _share_torch_hip_runtime()
         lib = ct.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
