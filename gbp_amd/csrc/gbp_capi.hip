@@ -86,6 +86,9 @@ struct gbp_ba {
     FusedPlan fused;
     // timing of the dominant kernel
     bool timing = false;
+    int timing_every = 1, timing_tick = 0;       // events around every n-th launch of the dominant kernel (two event
+                                                 // records per sweep cost ~6 us of a 125 us sweep)
+    bool timing_now = false;
     std::vector<hipEvent_t> ev;                  // pairs
     size_t ev_used = 0;
     const char *dominant = "k_factor_tile";
@@ -135,9 +138,18 @@ static inline int grid_for(size_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
 // ------------------------------------------------------------------------------ launches --
 
+static bool timing_sample(gbp_ba *h)
+{
+    if (!h->timing) return false;
+    const bool now = (h->timing_tick % h->timing_every) == 0;
+    h->timing_tick++;
+    return now;
+}
+
 static int time_begin(gbp_ba *h)
 {
-    if (!h->timing) return GBP_OK;
+    h->timing_now = timing_sample(h);
+    if (!h->timing_now) return GBP_OK;
     if (h->ev_used + 2 > h->ev.size()) {
         for (int i = 0; i < 2; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev.push_back(e); }
     }
@@ -147,7 +159,7 @@ static int time_begin(gbp_ba *h)
 
 static int time_end(gbp_ba *h)
 {
-    if (!h->timing) return GBP_OK;
+    if (!h->timing_now) return GBP_OK;
     HIPCHK(hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     h->ev_used += 2;
     return GBP_OK;
@@ -221,7 +233,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
     if (finished) *finished = false;
     if (with_messages && h->fused.enabled) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->timing) {
+        if (timing_sample(h)) {
             if (h->ev_used + 2 > h->ev.size())
                 for (int i = 0; i < 2; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->ev.push_back(e); }
             e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
@@ -1034,6 +1046,8 @@ int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable)
     ENTER(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     h->timing = enable != 0;
+    h->timing_every = enable > 1 ? enable : 1;
+    h->timing_tick = 0;
     h->ev_used = 0;
     return GBP_OK;
 }

@@ -214,7 +214,8 @@ class BAEngine:
         self.load_state(np.load(path, allow_pickle=False))
 
     def set_kernel_timing(self, on):
-        check(self._lib.gbp_ba_set_kernel_timing(self._h, int(bool(on))))
+        """on = True / 1: events around every launch of the dominant kernel; on = n > 1: around every n-th launch."""
+        check(self._lib.gbp_ba_set_kernel_timing(self._h, int(on)))
 
     def kernel_timing(self):
         ms, n, name = ct.c_double(), ct.c_int32(), ct.c_char_p()

@@ -137,7 +137,8 @@ int gbp_ba_state_size(gbp_ba_t *h, uint64_t *bytes);
 int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes);
 int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes);
 
-/* instrumentation for bench.py: HIP-event time of the dominant (factor) kernel on the handle's stream */
+/* instrumentation for bench.py: HIP-event time of the dominant (factor) kernel on the handle's stream; enable = n > 1
+ * brackets only every n-th launch (two event records per sweep are not free: ~6 us of a 125 us sweep) */
 int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
 int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);
