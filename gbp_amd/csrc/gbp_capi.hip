@@ -493,7 +493,6 @@ int gbp_ba_sync(gbp_ba_t *h)
 
 static inline size_t n_slots(const gbp_ba *h) { return std::max<size_t>((size_t)h->p.T * WTILE, 1); }
 static inline size_t h_lin_at(size_t slot, int row) { return (((slot >> 6) * (LIN_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
-static inline size_t h_msg_at(size_t slot, int row) { return (((slot >> 6) * (MSG_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
 
 int gbp_ba_factor_lambda_max(gbp_ba_t *h, double *cam_max, double *lmk_max)
 {

@@ -50,15 +50,6 @@ struct FusedArgs {
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase
 };
 
-// Identity on `v` that the compiler must evaluate after `dep` exists: chains a load's address to a value so
-// the load cannot be scheduled earlier (register-pressure control, see k_sweep_wat).
-template <typename T>
-GBP_DEV T after(T v, double dep)
-{
-    asm volatile("" : "+v"(v) : "v"(dep));
-    return v;
-}
-
 GBP_DEV void wave_lds_sync()
 {
     // all LDS traffic of this wave issued so far has completed; nothing may be moved across
