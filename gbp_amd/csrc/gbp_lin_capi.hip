@@ -35,6 +35,8 @@ struct LinParams {
     double *bel;                 // [N][D + P + D]
     const double *prior;         // [N][D + P]
     const int *vptr, *vadj;      // CSR: variable -> (factor << 1 | side), ascending factor id
+    double *vmsg;                // [2F][D + P]: the same messages in VARIABLE-major (CSR edge) order, for the belief stage
+    const int *epos_a, *epos_b;  // [F]: CSR edge index of (factor, side)
 };
 
 template <int D> struct LinDims {
@@ -79,10 +81,38 @@ GBP_DEV void lin_schur(const double (&akk)[Sym<D>::size], const double (&akn)[D]
 template <int D>
 __global__ __launch_bounds__(64) void k_lin_factor(LinParams p)
 {
-    constexpr int P = LinDims<D>::P, REC = LinDims<D>::REC;
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= p.F) return;
+    constexpr int P = LinDims<D>::P, REC = LinDims<D>::REC, R = D + P;
+    __shared__ double tr[64 * R];                           // transposes a wave's messages for the variable-major copy
+    __shared__ int tp[64];
+    const int lane = threadIdx.x;
+    const int nlive = min(64, p.F - (int)blockIdx.x * 64);  // factors of this wave (> 0 by the launch grid)
+    const int f = blockIdx.x * 64 + min(lane, nlive - 1);   // lanes past the end redo the last factor and store nothing
+    const bool live = lane < nlive;
     const size_t F = (size_t)p.F;
+    // the belief stage reads messages in CSR edge order: stage this wave's 64 records in LDS and write them out as
+    // contiguous (D+P)-double runs, 64/(D+P) records per store instruction (a lane-per-record store would touch 64 lines)
+    auto stage_out = [&](const double (&eta)[D], const double (&lam)[P], const int *epos) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) tr[lane * R + k] = eta[k];
+#pragma unroll
+        for (int k = 0; k < P; ++k) tr[lane * R + D + k] = lam[k];
+        tp[lane] = epos[f];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave per block
+        constexpr int G = 64 / R;
+        const int g = lane / R, k = lane - g * R;
+        if (g < G) {
+            if (nlive == 64) {                              // full wave: fixed trip count, LDS reads batched ahead of the stores
+#pragma unroll
+                for (int j0 = 0; j0 < 64; j0 += G) {
+                    const int j = j0 + g;
+                    if (j < 64) p.vmsg[(size_t)tp[j] * R + k] = tr[j * R + k];
+                }
+            } else {
+                for (int j = g; j < nlive; j += G) p.vmsg[(size_t)tp[j] * R + k] = tr[j * R + k];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     const double *ra = p.bel + (size_t)p.va[f] * REC, *rb = p.bel + (size_t)p.vb[f] * REC;
     // cavities: belief minus this factor's old message (gbp.py:341-350)
     double cea[D], cla[P], ceb[D], clb[P], oea[D], oeb[D];
@@ -113,9 +143,14 @@ __global__ __launch_bounds__(64) void k_lin_factor(LinParams p)
     for (int k = 0; k < D; ++k) en[k] = fb[k] + ceb[k];
     lin_schur<D>(aaa, aab, S, fa, en, lam, eta);
 #pragma unroll
-    for (int k = 0; k < D; ++k) p.msg_a[k * F + f] = (1.0 - d) * eta[k] + d * oea[k];      // gbp.py:368
+    for (int k = 0; k < D; ++k) eta[k] = (1.0 - d) * eta[k] + d * oea[k];                   // gbp.py:368
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < P; ++k) p.msg_a[(D + k) * F + f] = lam[k];
+        for (int k = 0; k < D; ++k) p.msg_a[k * F + f] = eta[k];
+#pragma unroll
+        for (int k = 0; k < P; ++k) p.msg_a[(D + k) * F + f] = lam[k];
+    }
+    stage_out(eta, lam, p.epos_a);
     // to b: eliminate a (from the OLD message of b: both are committed together, gbp.py:371-373 -- cea / cla were
     // formed before the store above)
 #pragma unroll
@@ -124,36 +159,50 @@ __global__ __launch_bounds__(64) void k_lin_factor(LinParams p)
     for (int k = 0; k < D; ++k) en[k] = fa[k] + cea[k];
     lin_schur<D>(abb, aba, S, fb, en, lam, eta);
 #pragma unroll
-    for (int k = 0; k < D; ++k) p.msg_b[k * F + f] = (1.0 - d) * eta[k] + d * oeb[k];
+    for (int k = 0; k < D; ++k) eta[k] = (1.0 - d) * eta[k] + d * oeb[k];
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < P; ++k) p.msg_b[(D + k) * F + f] = lam[k];
+        for (int k = 0; k < D; ++k) p.msg_b[k * F + f] = eta[k];
+#pragma unroll
+        for (int k = 0; k < P; ++k) p.msg_b[(D + k) * F + f] = lam[k];
+    }
+    stage_out(eta, lam, p.epos_b);
 }
 
+// 64/(D+P) variables per wave, one lane per (variable, belief entry): the variable's messages are one contiguous run of
+// vmsg (CSR edge order = adj_factors order), so the wave streams whole lines; the d x d solve is done by the entry-0 lane.
 template <int D>
 __global__ __launch_bounds__(64) void k_lin_belief(LinParams p)
 {
-    constexpr int P = LinDims<D>::P, REC = LinDims<D>::REC;
-    const int v = blockIdx.x * 64 + threadIdx.x;
-    if (v >= p.N) return;
-    const size_t F = (size_t)p.F;
-    double acc[D + P];
-#pragma unroll
-    for (int k = 0; k < D + P; ++k) acc[k] = p.prior[(size_t)v * (D + P) + k];
-    for (int e = p.vptr[v]; e < p.vptr[v + 1]; ++e) {            // adj_factors order (gbp.py:182-188)
-        const int fs = p.vadj[e], f = fs >> 1;
-        const double *m = (fs & 1) ? p.msg_b : p.msg_a;
-#pragma unroll
-        for (int k = 0; k < D + P; ++k) acc[k] += m[k * F + f];
+    constexpr int P = LinDims<D>::P, REC = LinDims<D>::REC, R = D + P, VPW = 64 / R;
+    __shared__ double sh[VPW * R];
+    const int lane = threadIdx.x, j = lane / R, k = lane - j * R;
+    const int v = blockIdx.x * VPW + j;
+    const bool on = j < VPW && v < p.N;
+    if (on) {
+        double acc = p.prior[(size_t)v * R + k];
+        const int e1 = p.vptr[v + 1];
+        int e = p.vptr[v];
+        for (; e + 3 < e1; e += 4) {                              // four loads in flight, added in adj_factors order (gbp.py:182-188)
+            const double m0 = p.vmsg[(size_t)e * R + k], m1 = p.vmsg[(size_t)(e + 1) * R + k], m2 = p.vmsg[(size_t)(e + 2) * R + k],
+                         m3 = p.vmsg[(size_t)(e + 3) * R + k];
+            acc += m0; acc += m1; acc += m2; acc += m3;
+        }
+        for (; e < e1; ++e) acc += p.vmsg[(size_t)e * R + k];
+        p.bel[(size_t)v * REC + k] = acc;
+        sh[j * R + k] = acc;
     }
-    double *rec = p.bel + (size_t)v * REC;
-    double eta[D], lam[P], mu[D];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave per block
+    if (on && k == 0) {
+        double eta[D], lam[P], mu[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { eta[k] = acc[k]; rec[k] = acc[k]; }
+        for (int i = 0; i < D; ++i) eta[i] = sh[j * R + i];
 #pragma unroll
-    for (int k = 0; k < P; ++k) { lam[k] = acc[D + k]; rec[D + k] = acc[D + k]; }
-    spd_solve<D>(lam, eta, mu);                                   // gbp.py:192-193
+        for (int i = 0; i < P; ++i) lam[i] = sh[j * R + D + i];
+        spd_solve<D>(lam, eta, mu);                               // gbp.py:192-193
 #pragma unroll
-    for (int k = 0; k < D; ++k) rec[D + P + k] = mu[k];
+        for (int i = 0; i < D; ++i) p.bel[(size_t)v * REC + R + i] = mu[i];
+    }
 }
 
 // sum over factors of 0.5 mu^T Lambda_f mu - eta_f^T mu + const = 0.5 |h(mu) - z|^2 / sigma^2 for linear h (gbp.py:36-44, 261-265)
@@ -241,7 +290,8 @@ static void lin_dispatch(int D, K &&k)
 static int lin_beliefs(gbp_lin *h)
 {
     if (h->p.N) lin_dispatch(h->D, [&](auto d) {
-        hipLaunchKernelGGL((k_lin_belief<decltype(d)::value>), dim3((h->p.N + 63) / 64), dim3(64), 0, h->stream, h->p);
+        constexpr int DD = decltype(d)::value, VPW = 64 / (DD + DD * (DD + 1) / 2);
+        hipLaunchKernelGGL((k_lin_belief<DD>), dim3((h->p.N + VPW - 1) / VPW), dim3(64), 0, h->stream, h->p);
     });
     LHIPCHK(hipGetLastError());
     h->has_beliefs = true;
@@ -284,9 +334,13 @@ static int lin_create_impl(gbp_lin *h, const gbp_lin_desc_t *d)
         if (d->factor_const) fconst[f] = d->factor_const[f];
     }
     for (int v = 0; v < N; ++v) vptr[v + 1] += vptr[v];
+    std::vector<int32_t> epos_a((size_t)F), epos_b((size_t)F);
     {
         std::vector<int32_t> fill(vptr.begin(), vptr.end() - 1);
-        for (int f = 0; f < F; ++f) { vadj[fill[va[f]]++] = f << 1; vadj[fill[vb[f]]++] = (f << 1) | 1; }
+        for (int f = 0; f < F; ++f) {
+            epos_a[f] = fill[va[f]]; vadj[fill[va[f]]++] = f << 1;
+            epos_b[f] = fill[vb[f]]; vadj[fill[vb[f]]++] = (f << 1) | 1;
+        }
     }
     std::vector<double> prior((size_t)N * (D + P)), zeros_msg((size_t)(D + P) * F, 0.0), zeros_bel((size_t)N * (D + P + D), 0.0);
     for (int v = 0; v < N; ++v) {
@@ -300,6 +354,12 @@ static int lin_create_impl(gbp_lin *h, const gbp_lin_desc_t *d)
     LCHK(lin_upload(h, &dva, va)); LCHK(lin_upload(h, &dvb, vb)); LCHK(lin_upload(h, &dvptr, vptr)); LCHK(lin_upload(h, &dvadj, vadj));
     LCHK(lin_upload(h, &dfeta, feta)); LCHK(lin_upload(h, &dflam, flam)); LCHK(lin_upload(h, &dfconst, fconst)); LCHK(lin_upload(h, &dprior, prior));
     LCHK(lin_upload(h, &p.msg_a, zeros_msg)); LCHK(lin_upload(h, &p.msg_b, zeros_msg)); LCHK(lin_upload(h, &p.bel, zeros_bel));
+    {
+        std::vector<double> zeros_v((size_t)2 * F * (D + P), 0.0);
+        int *dea, *deb;
+        LCHK(lin_upload(h, &p.vmsg, zeros_v)); LCHK(lin_upload(h, &dea, epos_a)); LCHK(lin_upload(h, &deb, epos_b));
+        p.epos_a = dea; p.epos_b = deb;
+    }
     p.va = dva; p.vb = dvb; p.vptr = dvptr; p.vadj = dvadj; p.feta = dfeta; p.flam = dflam; p.fconst = dfconst; p.prior = dprior;
     h->red_blocks = std::max(1, (F + 255) / 256);
     std::vector<double> zr((size_t)h->red_blocks, 0.0);

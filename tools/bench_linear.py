@@ -17,6 +17,7 @@ ap.add_argument('--dofs', type=int, default=3)
 ap.add_argument('--k', type=int, default=5)
 ap.add_argument('--steps', type=int, default=100)
 ap.add_argument('--warmup', type=int, default=10)
+ap.add_argument('--no-cpu-baseline', action='store_true')
 a = ap.parse_args()
 rs = np.random.RandomState(0)
 N, D, k = a.vars, a.dofs, a.k
@@ -36,8 +37,22 @@ e.iterate(a.warmup); e.sync()
 t0 = time.perf_counter(); e.iterate(a.steps); e.sync(); dt = time.perf_counter() - t0
 P = D * (D + 1) // 2
 bytes_sweep = 8 * (F * (D * (2 * D + 1) + 2 * D + 6 * (D + P) + 2 * (D + P)) + N * (2 * (D + P) + D))
+cpu = None
+if not a.no_cpu_baseline:
+    # bounded sample of the same workload for the numpy oracle (dense per-factor loops, one thread): the first 400 variables
+    # of the ring with their factors, 3 sweeps; reported per factor-sweep and scaled to this graph
+    from oracle.linear_oracle import LinearOracle
+    n_s = 400
+    sel = (va < n_s - k)
+    o = LinearOracle(va[sel], vb[sel], fe[sel], np.ascontiguousarray(fl[sel]), (mu0 / 3.0)[:n_s], np.ascontiguousarray(pl[:n_s]), factor_const=fc[sel])
+    o.update_all_beliefs(); o.synchronous_iteration()
+    tc = time.perf_counter(); o.iterate(3); tc = (time.perf_counter() - tc) / 3
+    us_per_factor = 1e6 * tc / int(sel.sum())
+    cpu = {"value": 1.0 / (us_per_factor * 1e-6 * F), "unit": "iter/s", "cores": 1, "kind": "port",
+           "sample": f"numpy oracle (oracle/linear_oracle.py) on the first {n_s} variables / {int(sel.sum())} factors of the same ring, "
+                     f"3 sweeps, {us_per_factor:.1f} us per factor-sweep, scaled to {F} factors"}
 print(json.dumps({"metric": "linear GBP sweeps/s", "value": a.steps / dt, "unit": "iter/s", "ms_per_step": 1e3 * dt / a.steps,
                   "config": {"workload": f"ring pose graph {N} vars x {D} dofs, {F} linear_displacement factors"},
                   "dtype": "f64", "roofline": {"bound": "hbm", "achieved": bytes_sweep * a.steps / dt / 1e9, "peak": 8000.0,
                                                "unit": "GB/s", "frac": bytes_sweep * a.steps / dt / 1e9 / 8000.0, "traffic": None},
-                  "energy_after": e.energy()}))
+                  "energy_after": e.energy(), "cpu_baseline": cpu}))
