@@ -5,9 +5,11 @@
 //   k_lin_factor<D>   one lane per factor: both outgoing messages from the OLD incoming ones
 //                     (Factor.compute_messages gbp.py:334-373): cavity of the other variable folded into its block,
 //                     that block eliminated by an unpivoted LDL^T (SPD: factor block + prior-backed cavity);
-//   k_lin_belief<D>   one lane per variable: prior + messages in adj_factors order, mean by a d x d solve
+//   k_lin_belief<D>   64/(d+P) variables per wave, one lane per belief entry: prior + messages in adj_factors order from
+//                     the variable-major copy of the messages (one contiguous run per variable), mean by a d x d solve
 //                     (VariableNode.update_belief gbp.py:176-198).
-// Layout: everything factor-indexed is SoA [row][F] (coalesced across lanes); beliefs are records [N][d + d(d+1)/2 + d]
+// Layout: everything factor-indexed is SoA [row][F] (coalesced across lanes); the new messages are ALSO written in CSR
+// edge order (vmsg, through an LDS transpose) for the belief stage; beliefs are records [N][d + d(d+1)/2 + d]
 // (eta | packed Lambda | mu) gathered per factor.  Lambda_f is constant: packed upper 2d x 2d, read every sweep.
 // HBM-bound like the BA sweep; d <= 6 keeps a factor's working set in registers (one wave per SIMD for d = 6).
 #include "../../include/gbp_ba.h"
