@@ -1,0 +1,142 @@
+"""The landmark-sharded driver with the REAL HIP engine at world sizes 2 and 3 on ONE GPU: every "rank" is a thread with
+its own BAEngine (own stream) on device 0, and the collectives are a lock-step test double of torch.distributed (shared
+slots + a barrier; gathers are concatenated in rank order exactly like all_gather_into_tensor).  This exercises what the
+1-GPU box cannot do with RCCL: gbp_ba_shard_begin / gbp_ba_shard_end with n_ranks > 1 on real kernels (fused and general
+sweeps), the partition, the MAX all-reduce of generate_priors_var and the globally normalised diagnostics."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import DATA, rel_err_rows
+from gbp_amd.balio import read_bal
+from gbp_amd.synthetic import make_synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+class LockstepWorld:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class LockstepDist:
+    """The subset of torch.distributed that gbp_amd.sharded.ShardedBA uses, for threads of one process."""
+
+    class ReduceOp:
+        SUM, MAX = 'sum', 'max'
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank = shared, rank
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.shared.world
+
+    def _exchange(self, tensor):
+        import torch
+        torch.cuda.current_stream().synchronize()            # the producer kernels of this rank
+        self.shared.slots[self.rank] = tensor
+        self.shared.barrier.wait()
+        parts = [t.clone() for t in self.shared.slots]
+        torch.cuda.current_stream().synchronize()
+        self.shared.barrier.wait()                           # everybody has copied before anyone overwrites
+        return parts
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+        out.copy_(torch.cat(self._exchange(inp)))
+
+    def all_reduce(self, t, op=None):
+        import torch
+        parts = torch.stack(self._exchange(t))
+        t.copy_(parts.max(dim=0).values if op == 'max' else parts.sum(dim=0))
+
+
+def run_world(problem, world, fused, n_sweeps, oracle_mod):
+    from gbp_amd.sharded import ShardedBA
+    shared = LockstepWorld(world)
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            g = ShardedBA(problem, device=0, fused=fused, dist=LockstepDist(shared, r))
+            g.generate_priors_var(50.0)
+            g.update_all_beliefs()
+            ares, energies = oracle_mod.replay_ba(g, n_sweeps, diagnostics=True)
+            ce, cl = g.camera_beliefs()
+            rng, le, ll = g.local_landmark_beliefs()
+            out[r] = dict(ce=ce, cl=cl, le=le, ll=ll, rng=rng, ares=ares, energies=energies, F=g.F, fused=g.info()['fused'])
+        except BaseException as e:                           # noqa: BLE001 -- surface it in the main thread
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    if errors:
+        raise errors[0]
+    return out
+
+
+@pytest.mark.parametrize('world,fused', [(2, True), (3, True), (2, False)])
+def test_sharded_engine_matches_single_engine(oracle_mod, world, fused):
+    from gbp_amd.engine import BAEngine
+    p = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
+    ref = BAEngine.from_problem(p, fused=fused)
+    ref.generate_priors_var(50.0)
+    ref.update_all_beliefs()
+    ares, energies = oracle_mod.replay_ba(ref, 14, diagnostics=True)
+    rce, rcl, rle, rll = ref.beliefs()
+    ranks = run_world(p, world, fused, 14, oracle_mod)
+    assert sum(r['F'] for r in ranks) == p.n_factors
+    lo = 0
+    for r in ranks:
+        assert r['fused'] == fused
+        assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])   # identical on every rank
+        assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
+        a, b = r['rng']
+        assert a == lo
+        lo = b
+        assert rel_err_rows(r['le'], rle[a:b]) < 1e-6 and rel_err_rows(r['ll'], rll[a:b]) < 1e-6
+        assert np.allclose(r['ares'], ares, rtol=1e-7) and np.allclose(r['energies'], energies, rtol=1e-7)
+    assert lo == p.n_lmks
+
+
+def test_sharded_engine_synthetic_two_ranks(oracle_mod):
+    """A bigger, regular graph (8k factors per rank, several tiles per workgroup) through the fused shard kernels."""
+    from gbp_amd.engine import BAEngine
+    p = make_synthetic(n_cams=40, n_lmks=1600, obs_per_lmk=10, seed=4)
+    ref = BAEngine.from_problem(p)
+    ref.generate_priors_var(50.0); ref.update_all_beliefs(); ref.iterate(8)
+    rce, rcl, rle, rll = ref.beliefs()
+    shared_ranks = []
+    from gbp_amd.sharded import ShardedBA
+    shared = LockstepWorld(2)
+    errors = []
+
+    def rank_main(r):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            g = ShardedBA(p, device=0, dist=LockstepDist(shared, r))
+            g.generate_priors_var(50.0); g.update_all_beliefs(); g.iterate(8)
+            shared_ranks.append((r, g.camera_beliefs(), g.local_landmark_beliefs()))
+        except BaseException as e:                           # noqa: BLE001
+            errors.append(e); shared.barrier.abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]; [t.join(300) for t in ts]
+    if errors:
+        raise errors[0]
+    for r, (ce, cl), ((a, b), le, ll) in shared_ranks:
+        assert rel_err_rows(ce, rce) < 1e-6 and rel_err_rows(cl, rcl) < 1e-6
+        assert rel_err_rows(le, rle[a:b]) < 1e-6 and rel_err_rows(ll, rll[a:b]) < 1e-6
