@@ -77,6 +77,7 @@ struct gbp_ba {
     int *d_ids = nullptr; size_t ids_cap = 0;
     std::vector<void *> allocs;
     bool has_beliefs = false;
+    bool resid_ok = false; double resid[2] = {0.0, 0.0};     // ARE / energy sums of the CURRENT state (ba.py asks for both every sweep)
     // streaming means export (viewer): device staging, two pinned host mirrors, a copy stream
     double *d_mu = nullptr, *h_mu[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
@@ -535,6 +536,7 @@ static int upload_lmk_priors(gbp_ba *h, const std::vector<double> &pri)
 int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double *lmk_lambda)
 {
     ENTER(h);
+    h->resid_ok = false;
     const Params &p = h->p;
     if (!cam_lambda || !lmk_lambda) return fail(GBP_EINVAL, "null argument");
     std::vector<double> cb, lr;
@@ -560,6 +562,7 @@ int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double
 int gbp_ba_generate_priors(gbp_ba_t *h, double weaker_factor)
 {
     ENTER(h);
+    h->resid_ok = false;
     if (!(weaker_factor != 0.0)) return fail(GBP_EINVAL, "weaker_factor must be non-zero");
     std::vector<double> cm((size_t)h->p.C), lm((size_t)h->p.L);
     CHK(gbp_ba_factor_lambda_max(h, cm.data(), lm.data()));
@@ -572,6 +575,7 @@ int gbp_ba_generate_priors(gbp_ba_t *h, double weaker_factor)
 int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam, const double *lmk_eta, const double *lmk_lam)
 {
     ENTER(h);
+    h->resid_ok = false;
     const Params &p = h->p;
     if (!cam_eta || !cam_lam || !lmk_eta || !lmk_lam) return fail(GBP_EINVAL, "null argument");
     std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp((size_t)std::max(p.L, 1) * 9, 0.0);
@@ -594,6 +598,7 @@ int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam,
 int gbp_ba_weaken_priors(gbp_ba_t *h, double factor)
 {
     ENTER(h);
+    h->resid_ok = false;
     const Params &p = h->p;
     const size_t n = (size_t)p.C * 27 + (size_t)p.L * 9;
     if (n) hipLaunchKernelGGL(k_weaken_priors, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, factor);
@@ -606,6 +611,7 @@ int gbp_ba_weaken_priors(gbp_ba_t *h, double factor)
 int gbp_ba_update_beliefs(gbp_ba_t *h)
 {
     ENTER(h);
+    h->resid_ok = false;
     CHK(sweep_begin(h, 0, 0, 0, h->d_partial));
     CHK(launch_cam_finish(h, h->d_partial, 1, 0));
     h->has_beliefs = true;
@@ -615,6 +621,7 @@ int gbp_ba_update_beliefs(gbp_ba_t *h)
 int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin)
 {
     ENTER(h);
+    h->resid_ok = false;
     if (n_iters < 0) return fail(GBP_EINVAL, "n_iters < 0");
     for (int it = 0; it < n_iters; ++it) {
         bool finished = false;
@@ -628,6 +635,7 @@ int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t loca
 int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, int32_t local_relin, double *partial_dev)
 {
     ENTER(h);
+    h->resid_ok = false;
     if (!partial_dev) return fail(GBP_EINVAL, "null partial buffer");
     return sweep_begin(h, with_messages, robustify, local_relin, partial_dev);
 }
@@ -635,6 +643,7 @@ int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, in
 int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks)
 {
     ENTER(h);
+    h->resid_ok = false;
     if (!gathered_dev || n_ranks < 1) return fail(GBP_EINVAL, "bad gathered buffer / rank count");
     CHK(launch_cam_finish(h, gathered_dev, n_ranks, (size_t)h->p.C * 27));
     h->has_beliefs = true;
@@ -650,12 +659,17 @@ int gbp_ba_residual_sums(gbp_ba_t *h, double out[2])
     const Params &p = h->p;
     out[0] = out[1] = 0.0;
     if (!p.F) return GBP_OK;
-    const int nb = grid_for(n_slots(h));
-    hipLaunchKernelGGL(k_residual, dim3(nb), dim3(BLOCK), 0, h->stream, p, h->d_red);
-    HIPCHK(hipGetLastError());
-    std::vector<double> part;
-    CHK(download(h, part, h->d_red, 2 * (size_t)nb));
-    for (int b = 0; b < nb; ++b) { out[0] += part[2 * b]; out[1] += part[2 * b + 1]; }
+    if (!h->resid_ok) {                                 // are() then energy() on the same state: one kernel, one round trip
+        const int nb = grid_for(n_slots(h));
+        hipLaunchKernelGGL(k_residual, dim3(nb), dim3(BLOCK), 0, h->stream, p, h->d_red);
+        HIPCHK(hipGetLastError());
+        std::vector<double> part;
+        CHK(download(h, part, h->d_red, 2 * (size_t)nb));
+        h->resid[0] = h->resid[1] = 0.0;
+        for (int b = 0; b < nb; ++b) { h->resid[0] += part[2 * b]; h->resid[1] += part[2 * b + 1]; }
+        h->resid_ok = true;
+    }
+    out[0] = h->resid[0]; out[1] = h->resid[1];
     return GBP_OK;
 }
 
@@ -1019,6 +1033,7 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
 int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
 {
     ENTER(h);
+    h->resid_ok = false;
     uint64_t need = 0;
     CHK(gbp_ba_state_size(h, &need));
     if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
