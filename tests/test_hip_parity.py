@@ -456,3 +456,37 @@ def test_streaming_means_snapshot(eng_mod):
     got2 = e.means_fetch(wait=True)
     for a, b in zip(got2, want2):
         assert np.array_equal(a, b)
+
+
+def test_full_size_against_oracle_and_reference(eng_mod, oracle_mod):
+    """The headline graph itself (500 x 100k x 1M): three sweeps of the fused engine against the C oracle (OpenMP) on all
+    1.1M variables, and -- fixture G9b, generated by tests/golden/make_g9b.py -- against the REFERENCE's own beliefs of
+    all 500 cameras and 2000 sampled landmarks after update_all_beliefs and after sweeps 1 and 2."""
+    p = make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'G9b_synthetic_full_1000000.npz')
+    g9b = np.load(path) if os.path.exists(path) else None
+    o = oracle_mod.OracleBA.from_problem(p, threads=max(1, min(32, len(os.sched_getaffinity(0)))))
+    e = eng_mod.BAEngine.from_problem(p)
+    assert e.info()['fused']
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+
+    def check(tag):
+        eb = e.beliefs()
+        assert max(rel_err_rows(a, b) for a, b in zip(eb, o.beliefs())) < BELIEF_TOL
+        if g9b is not None:
+            s = g9b['lmk_sample']
+            got = (eb[0], eb[1], eb[2][s], eb[3][s])
+            want = (g9b[tag + '_cam_eta'], g9b[tag + '_cam_lam'], g9b[tag + '_lmk_eta'], g9b[tag + '_lmk_lam'])
+            assert max(rel_err_rows(a, b) for a, b in zip(got, want)) < BELIEF_TOL
+            assert e.are() == pytest.approx(float(g9b[tag + '_are']), rel=1e-8)
+
+    check('it0')
+    for it in (1, 2, 3):
+        for g in (o, e):
+            g.synchronous_iteration(robustify=True, local_relin=True)
+        if it <= 2:
+            check(f'it{it}')
+    assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())) < BELIEF_TOL
+    assert e.are() == pytest.approx(o.are(), rel=1e-8)
