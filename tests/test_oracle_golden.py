@@ -169,3 +169,25 @@ def test_g9_synthetic_generator_and_engine(oracle_mod):
     assert belief_gap(snaps[1], g, 'it1_') < 1e-7
     assert belief_gap(snaps[5], g, 'it5_') < 1e-6
     assert belief_gap(snaps[20], g, 'it20_') < 1e-6
+
+
+def test_g9b_full_size_reference_beliefs(oracle_mod):
+    """Fixture G9b: the reference itself on the full headline graph (500 x 100k x 1M, tests/golden/make_g9b.py, 193 s per
+    sweep): the oracle reproduces all 500 camera beliefs and the 2000 sampled landmark beliefs after update_all_beliefs
+    and after sweeps 1 and 2."""
+    from gbp_amd.synthetic import make_synthetic
+    g = golden('G9b_synthetic_full_1000000')
+    p = make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0)
+    o = oracle_mod.OracleBA.from_problem(p, threads=min(8, len(os.sched_getaffinity(0))))
+    o.generate_priors_var(50.0)
+    o.update_all_beliefs()
+    s = g['lmk_sample']
+    for it in (0, 1, 2):
+        if it:
+            o.synchronous_iteration(robustify=True, local_relin=True)
+        ce, cl, le, ll = o.beliefs()
+        tag = f'it{it}_'
+        gap = max(rel_err_rows(ce, g[tag + 'cam_eta']), rel_err_rows(cl, g[tag + 'cam_lam']),
+                  rel_err_rows(le[s], g[tag + 'lmk_eta']), rel_err_rows(ll[s], g[tag + 'lmk_lam']))
+        assert gap < 1e-8, (it, gap)
+        assert o.are() == pytest.approx(float(g[tag + 'are']), rel=1e-9)
