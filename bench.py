@@ -21,7 +21,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-TIMING_EVERY = 8
+TIMING_EVERY = 25
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 
 
@@ -133,7 +133,8 @@ def main():
 
     graph.iterate(args.warmup)
     graph.sync()
-    # HIP events around every 8th launch of the dominant kernel: bracketing all of them costs ~6 us per 125 us sweep
+    # HIP events around every 25th launch of the dominant kernel (8 samples per 200 steps): bracketing all of them costs ~6 us per
+    # 125 us sweep, every 8th still ~2 us
     graph.set_kernel_timing(0 if os.environ.get('GBP_BENCH_NO_KERNEL_TIMING') else TIMING_EVERY)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
