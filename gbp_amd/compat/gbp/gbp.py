@@ -102,6 +102,12 @@ class FactorGraph:
                     lam[go:go + d, go2:go2 + d2] += f.factor.lam[fo:fo + d, fo2:fo2 + d2]
         return eta, lam
 
+    def device_engine(self, device=0):
+        """No reference counterpart: this LINEAR graph (nonlinear_factors=False, two-variable factors, d <= 6) on the MI355X
+        (include/gbp_lin.h).  Call after compute_all_factors(); the host graph is left untouched."""
+        from gbp_amd.linear import LinearEngine
+        return LinearEngine.from_factor_graph(self, device=device)
+
     def joint_distribution_cov(self):
         eta, lam = self.joint_distribution_inf()
         sigma = np.linalg.inv(lam)

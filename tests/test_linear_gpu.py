@@ -102,7 +102,8 @@ def test_from_host_factor_graph_and_errors():
                     f += 1
         graph.update_all_beliefs()
         graph.compute_all_factors()
-        e = LinearEngine.from_factor_graph(graph)
+        e = graph.device_engine()
+        assert isinstance(e, LinearEngine)
         e.update_all_beliefs()
         for _ in range(10):
             graph.synchronous_iteration()
