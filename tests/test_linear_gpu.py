@@ -124,3 +124,23 @@ def test_from_host_factor_graph_and_errors():
     fresh = LinearEngine([0], [1], np.zeros((1, 4)), np.tile(np.eye(4), (1, 1, 1)), np.zeros((2, 2)), np.tile(np.eye(2), (2, 1, 1)))
     with pytest.raises(_capi.GbpError):
         fresh.iterate(1)                                                                                                   # no beliefs yet
+
+
+def test_device_engine_prints_the_reference_stdout_trace():
+    """The 'Iteration i // Energy ... // Av distance of means from MAP ...' lines of the reference's own
+    `ndim_posegraph.py --n_varnodes 100 --dim 3 --n_iters 20` run (fixture G8 stdout), reproduced character for character
+    with the sweeps on the device engine."""
+    from gbp_amd.linear import LinearEngine
+    from oracle.linear_oracle import toy_posegraph
+    g8 = golden('G8_toy_linear')
+    want = [ln for ln in str(g8['n100d3_stdout']).split('\n') if ln.startswith('Iteration')]
+    va, vb, fe, fl, fc, pe, pl = toy_posegraph(100, 3, 10, 1.0, seed=0)
+    e = LinearEngine(va, vb, fe, fl, pe, pl, factor_const=fc)
+    e.update_all_beliefs()
+    mu = g8['n100d3_map_mu']
+    got = []
+    for i in range(20):
+        e.synchronous_iteration()
+        got.append(f'Iteration {i}   //   Energy {e.energy():.4f}   //   '
+                   f'Av distance of means from MAP {np.linalg.norm(e.get_means() - mu):4f}')     # ndim_posegraph.py:107-108
+    assert got == want
