@@ -16,6 +16,23 @@ _bp = ct.POINTER(ct.c_uint8)
 LOSS = {None: 0, 'None': 0, 'none': 0, 'huber': 1, 'constant': 2}
 FLAG_NO_FUSED = 1
 CAM_PARTIAL_DOUBLES = 27
+COMM_ID_BYTES = 128
+XCH_ALWAYS = 1
+EXCHANGE_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint64, ct.c_void_p)
+
+
+def torch_rccl_path():
+    """PyTorch's bundled librccl.so when torch is installed (the build that matches the HIP runtime torch maps), else None
+    (the library then takes whatever librccl the process holds, or the system one)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin or os.environ.get('GBP_SYSTEM_HIP'):
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), 'lib', 'librccl.so')
+    return path.encode() if os.path.exists(path) else None
 
 
 class Desc(ct.Structure):
@@ -59,10 +76,21 @@ SIGNATURES = {
     'gbp_ba_get_messages': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, _dp, _dp, _dp, _dp]),
     'gbp_ba_get_factors': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, _dp, _dp, _dp, _ip, _ip, _dp]),
     'gbp_ba_get_relin_state': (ct.c_int, [ct.c_void_p, _ip, _dp, _dp, _bp]),
+    'gbp_ba_get_relin_state_range': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, _ip, _dp, _dp, _bp]),
+    'gbp_ba_count_relinearising': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int64)]),
+    'gbp_ba_get_relin_counts': (ct.c_int, [ct.c_void_p, _ip, ct.c_int32]),
+    'gbp_ba_eval_fn': (ct.c_int, [_dp, ct.c_int32, _dp, _dp, _dp, _dp, ct.c_int32]),
+    'gbp_ba_get_kernel_times': (ct.c_int, [ct.c_void_p, _dp, ct.c_int32, ct.POINTER(ct.c_int32)]),
     'gbp_ba_set_iters_since_relin': (ct.c_int, [ct.c_void_p, _ip]),
     'gbp_ba_fill_iters_since_relin': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_shard_begin': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_void_p]),
     'gbp_ba_shard_end': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32]),
+    'gbp_ba_comm_unique_id': (ct.c_int, [ct.c_void_p, ct.c_char_p]),
+    'gbp_ba_comm_init_rccl': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_char_p]),
+    'gbp_ba_set_exchange': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
+    'gbp_ba_comm_destroy': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_iterate_sharded': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
+    'gbp_ba_update_beliefs_sharded': (ct.c_int, [ct.c_void_p]),
     'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_get_kernel_timing': (ct.c_int, [ct.c_void_p, _dp, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_char_p)]),
     'gbp_ba_means_snapshot': (ct.c_int, [ct.c_void_p]),
@@ -81,6 +109,7 @@ SIGNATURES = {
     'gbp_lin_get_beliefs': (ct.c_int, [ct.c_void_p, _dp, _dp]),
     'gbp_lin_get_means': (ct.c_int, [ct.c_void_p, _dp]),
     'gbp_lin_get_messages': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
+    'gbp_ba_fused_max_cams': (ct.c_int, []),
     'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
 }
 

@@ -9,6 +9,9 @@
 #include "gbp_fused.hpp"
 #include "gbp_balio.hpp"
 
+#include <rccl/rccl.h>      // types only: the library is dlopen()ed when a communicator is asked for (no link-time dependency)
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -74,7 +77,6 @@ struct gbp_ba {
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
     double *d_tmp = nullptr; size_t tmp_bytes = 0;
-    int *d_ids = nullptr; size_t ids_cap = 0;
     std::vector<void *> allocs;
     bool has_beliefs = false;
     bool resid_ok = false; double resid[2] = {0.0, 0.0};     // ARE / energy sums of the CURRENT state (ba.py asks for both every sweep)
@@ -93,7 +95,21 @@ struct gbp_ba {
     std::vector<hipEvent_t> ev;                  // pairs
     size_t ev_used = 0;
     const char *dominant = "k_factor_tile";
+    // per-sweep count of relinearising factors: ring of device counters, half of it cleared whenever the sweep index
+    // enters it, so the last RELIN_RING/2 sweeps are always readable
+    int *d_relin_ring = nullptr;
+    long sweep_count = 0;
+    int *d_count = nullptr;                      // scratch counter of gbp_ba_count_relinearising
+    // landmark-sharded sweep: the camera exchange (include/gbp_ba.h gbp_ba_set_exchange / gbp_ba_comm_init_rccl)
+    gbp_exchange_fn xch_fn = nullptr;
+    void *xch_ctx = nullptr;
+    int xch_rank = 0, xch_ranks = 1, xch_flags = 0;
+    double *d_send = nullptr, *d_recv = nullptr; // C*27 and n_ranks*C*27
+    ncclComm_t comm = nullptr;
+    hipStream_t side_stream = nullptr;           // beliefs of over-sized landmarks run beside the exchange
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
+constexpr int RELIN_RING = 1024;
 
 template <typename T>
 static int dev_alloc(gbp_ba *h, T **out, size_t n, bool zero = true)
@@ -228,10 +244,28 @@ static int ensure_staging(gbp_ba *h)
 
 // one synchronous_iteration's device work up to (and including) this rank's camera partial sums; with finish != 0 the
 // camera beliefs are completed as well (single GPU) and *finished tells the caller so
+static int launch_big_lmk_beliefs(gbp_ba *h, hipStream_t stream)
+{
+    const int *list = h->fused.enabled ? h->fused.d_big : h->d_big;
+    const int n = (int)h->big_lmks.size();
+    if (!n || !list) return GBP_OK;
+    hipLaunchKernelGGL(k_lmk_belief_list, dim3((n + 63) / 64), dim3(64), 0, stream, h->p, list, n);
+    HIPCHK(hipGetLastError());
+    return GBP_OK;
+}
+
+// defer_big: leave the beliefs of the over-sized landmarks (k_lmk_belief_list) to the caller, who runs them beside the
+// camera exchange (launch_big_lmk_beliefs)
 static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish = 0,
-                       bool *finished = nullptr)
+                       bool *finished = nullptr, bool defer_big = false)
 {
     if (finished) *finished = false;
+    if (with_messages) {
+        const int slot = (int)(h->sweep_count % RELIN_RING);
+        if (slot % (RELIN_RING / 2) == 0) HIPCHK(hipMemsetAsync(h->d_relin_ring + slot, 0, sizeof(int) * (RELIN_RING / 2), h->stream));
+        h->p.relin_slot = h->d_relin_ring + slot;
+        h->sweep_count++;
+    }
     if (with_messages && h->fused.enabled) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing_sample(h)) {
@@ -240,7 +274,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
             e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
             h->ev_used += 2;
         }
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1);
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big);
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (finished) *finished = finish != 0;
         return GBP_OK;
@@ -249,11 +283,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         // tile sweep: messages + the tiles' landmark beliefs + camera messages staged camera-major
         CHK(ensure_staging(h));
         CHK(launch_factor_stage(h, robustify, local_relin));
-        if (!h->big_lmks.empty()) {
-            hipLaunchKernelGGL(k_lmk_belief_list, dim3(((int)h->big_lmks.size() + 63) / 64), dim3(64), 0, h->stream, h->p, h->d_big,
-                               (int)h->big_lmks.size());
-            HIPCHK(hipGetLastError());
-        }
+        if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
         if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(1024), 0, h->stream, h->p, partial);
         HIPCHK(hipGetLastError());
         return GBP_OK;
@@ -261,6 +291,64 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
     CHK(launch_lmk_beliefs(h));                 // update_all_beliefs: from the stored messages
     CHK(launch_cam_partial(h, partial));
     return GBP_OK;
+}
+
+// ------------------------------------------------------------------------------- RCCL ------
+// Resolved at run time: a process that never shards never maps librccl.  When PyTorch is in the process its bundled
+// librccl.so is already mapped (and is the build that matches the HIP runtime torch brought along, see
+// gbp_amd/_capi.py), so that one is taken; otherwise the system library.
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load(const char *path)
+{
+    if (g_rccl.lib) return GBP_OK;
+    void *lib = nullptr;
+    if (path && *path) lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (int pass = 0; pass < 2 && !lib; ++pass)              // first whatever the process already holds, then a fresh load
+        for (const char *nm : names) {
+            lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (lib) break;
+        }
+    if (!lib) return fail(GBP_ESTATE, "librccl.so could not be loaded: %s", dlerror());
+    Rccl r;
+    r.lib = lib;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(lib, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+        return fail(GBP_ESTATE, "librccl.so lacks an expected entry point");
+    g_rccl = r;
+    return GBP_OK;
+}
+
+// gbp_exchange_fn over an RCCL communicator: one all-gather of C*27 doubles per rank, in stream order
+int rccl_exchange(void *ctx, const double *send_dev, double *recv_dev, uint64_t count, void *stream)
+{
+    gbp_ba *h = static_cast<gbp_ba *>(ctx);
+    const ncclResult_t rc = g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclDouble, h->comm, static_cast<hipStream_t>(stream));
+    if (rc != ncclSuccess) return fail(GBP_EHIP, "ncclAllGather failed: %s", g_rccl.GetErrorString(rc));
+    return GBP_OK;
+}
+}  // namespace
+
+static void shard_comm_release(gbp_ba *h)
+{
+    if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); (void)g_rccl.CommDestroy(h->comm); }
+    h->comm = nullptr;
+    if (h->xch_fn == rccl_exchange) { h->xch_fn = nullptr; h->xch_ctx = nullptr; h->xch_ranks = 1; h->xch_rank = 0; }
 }
 
 // ------------------------------------------------------------------------------- C ABI ----
@@ -277,11 +365,16 @@ void gbp_ba_destroy(gbp_ba_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *ptr : h->allocs) (void)hipFree(ptr);
     if (h->d_tmp) (void)hipFree(h->d_tmp);
-    if (h->d_ids) (void)hipFree(h->d_ids);
+    if (h->d_send) (void)hipFree(h->d_send);
+    if (h->d_recv) (void)hipFree(h->d_recv);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     for (int i = 0; i < 2; ++i) { if (h->h_mu[i]) (void)hipHostFree(h->h_mu[i]); if (h->ev_landed[i]) (void)hipEventDestroy(h->ev_landed[i]); }
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
+    shard_comm_release(h);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     fused_destroy(h->fused);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -320,6 +413,8 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
                         i, d->cam_idx[i], d->lmk_idx[i], C, L);
         h->h_cptr[(size_t)d->cam_idx[i] + 1]++;
     }
+    if (d->num_undamped_iters > ITERS_MAX || d->min_linear_iters > ITERS_MAX)
+        return fail(GBP_EINVAL, "num_undamped_iters / min_linear_iters above %d are not supported (iters_since_relin saturates there)", ITERS_MAX);
     if (C >= (1 << (32 - META_LMK_BITS))) return fail(GBP_EINVAL, "more than %d cameras are not supported", (1 << (32 - META_LMK_BITS)) - 1);
     for (int c = 0; c < C; ++c) h->h_cptr[c + 1] += h->h_cptr[c];
     std::vector<int32_t> ref_file((size_t)F);
@@ -438,6 +533,8 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     p.cptr = cptr; p.cadj = cadj;
 
     CHK(dev_alloc(h, &h->d_partial, (size_t)std::max(C, 1) * 27));
+    CHK(dev_alloc(h, &h->d_relin_ring, (size_t)RELIN_RING));
+    CHK(dev_alloc(h, &h->d_count, 1));
     CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(std::max<size_t>(S, 1))));
 
     if (!(h->flags & GBP_FLAG_NO_FUSED)) {
@@ -650,6 +747,113 @@ int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks)
     return GBP_OK;
 }
 
+static int shard_buffers(gbp_ba *h, int n_ranks)
+{
+    const size_t n = (size_t)std::max(h->p.C, 1) * 27;
+    if (h->d_send) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->d_send)); HIPCHK(hipFree(h->d_recv)); h->d_send = h->d_recv = nullptr; }
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_send), n * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_recv), n * sizeof(double) * (size_t)n_ranks));
+    return GBP_OK;
+}
+
+int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank, int32_t n_ranks, int32_t flags)
+{
+    ENTER(h);
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GBP_EINVAL, "rank %d of %d", rank, n_ranks);
+    if (!fn && n_ranks > 1) return fail(GBP_EINVAL, "an exchange function is needed for more than one rank");
+    shard_comm_release(h);
+    CHK(shard_buffers(h, n_ranks));
+    h->xch_fn = fn; h->xch_ctx = ctx; h->xch_rank = rank; h->xch_ranks = n_ranks; h->xch_flags = flags;
+    return GBP_OK;
+}
+
+int gbp_ba_comm_unique_id(void *id128, const char *rccl_path)
+{
+    if (!id128) return fail(GBP_EINVAL, "null argument");
+    CHK(rccl_load(rccl_path));
+    ncclUniqueId id;
+    const ncclResult_t rc = g_rccl.GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(GBP_EHIP, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(rc));
+    static_assert(sizeof(id) == GBP_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id128, &id, sizeof id);
+    return GBP_OK;
+}
+
+int gbp_ba_comm_init_rccl(gbp_ba_t *h, const void *id128, int32_t rank, int32_t n_ranks, int32_t flags, const char *rccl_path)
+{
+    ENTER(h);
+    if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GBP_EINVAL, "bad communicator arguments (rank %d of %d)", rank, n_ranks);
+    CHK(rccl_load(rccl_path));
+    shard_comm_release(h);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    const ncclResult_t rc = g_rccl.CommInitRank(&h->comm, n_ranks, id, rank);
+    if (rc != ncclSuccess) { h->comm = nullptr; return fail(GBP_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(rc)); }
+    CHK(shard_buffers(h, n_ranks));
+    h->xch_fn = rccl_exchange; h->xch_ctx = h; h->xch_rank = rank; h->xch_ranks = n_ranks; h->xch_flags = flags;
+    return GBP_OK;
+}
+
+int gbp_ba_comm_destroy(gbp_ba_t *h)
+{
+    ENTER(h);
+    shard_comm_release(h);
+    return GBP_OK;
+}
+
+// one sharded sweep (or belief update) on the handle's stream: local kernels -> camera partial sums -> exchange -> rank-ordered
+// sum + prior + 6x6 solve.  With one rank and no GBP_XCH_ALWAYS nothing is exchanged and the camera beliefs are finished by
+// the reduce launch itself, exactly like gbp_ba_iterate.
+static int sharded_step(gbp_ba *h, int with_messages, int robustify, int local_relin)
+{
+    const bool exchange = h->xch_ranks > 1 || ((h->xch_flags & GBP_XCH_ALWAYS) && h->xch_fn);
+    if (!exchange) {
+        bool finished = false;
+        CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_partial, 1, &finished));
+        if (!finished) CHK(launch_cam_finish(h, h->d_partial, 1, 0));
+        return GBP_OK;
+    }
+    const bool big = with_messages && !h->big_lmks.empty();     // their beliefs need nothing from the exchange: side stream
+    CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, nullptr, big));
+    if (big) {
+        if (!h->side_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        CHK(launch_big_lmk_beliefs(h, h->side_stream));
+        HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
+    }
+    int rc = h->xch_fn(h->xch_ctx, h->d_send, h->d_recv, (uint64_t)h->p.C * 27, h->stream);
+    if (rc != GBP_OK) return rc < 0 ? rc : fail(GBP_EHIP, "the exchange function returned %d", rc);
+    CHK(launch_cam_finish(h, h->d_recv, h->xch_ranks, (size_t)h->p.C * 27));
+    if (big) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    return GBP_OK;
+}
+
+int gbp_ba_iterate_sharded(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    if (n_iters < 0) return fail(GBP_EINVAL, "n_iters < 0");
+    if (!h->d_send) return fail(GBP_ESTATE, "no exchange set (gbp_ba_comm_init_rccl / gbp_ba_set_exchange)");
+    for (int it = 0; it < n_iters; ++it) CHK(sharded_step(h, 1, robustify, local_relin));
+    h->has_beliefs = true;
+    return GBP_OK;
+}
+
+int gbp_ba_update_beliefs_sharded(gbp_ba_t *h)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    if (!h->d_send) return fail(GBP_ESTATE, "no exchange set (gbp_ba_comm_init_rccl / gbp_ba_set_exchange)");
+    CHK(sharded_step(h, 0, 0, 0));
+    h->has_beliefs = true;
+    return GBP_OK;
+}
+
 // --------------------------------------------------------------------------- diagnostics ---
 
 int gbp_ba_residual_sums(gbp_ba_t *h, double out[2])
@@ -777,15 +981,8 @@ int gbp_ba_get_messages(gbp_ba_t *h, int32_t f0, int32_t n, double *cam_eta, dou
     CHK(check_range(h, f0, n));
     const Params &p = h->p;
     if (!n || !(cam_eta || cam_lam || lmk_eta || lmk_lam)) return GBP_OK;
-    if ((size_t)n > h->ids_cap) {
-        if (h->d_ids) HIPCHK(hipFree(h->d_ids));
-        h->d_ids = nullptr; h->ids_cap = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_ids), sizeof(int) * (size_t)n));
-        h->ids_cap = n;
-    }
-    HIPCHK(hipMemcpyAsync(h->d_ids, h->ref2slot.data() + f0, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
     CHK(ensure_tmp(h, sizeof(double) * 36 * (size_t)n));
-    hipLaunchKernelGGL(k_export_messages, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, h->d_ids, n, h->d_tmp);
+    hipLaunchKernelGGL(k_export_messages, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, p.cadj + f0, n, h->d_tmp);
     HIPCHK(hipGetLastError());
     std::vector<double> m;
     CHK(download(h, m, h->d_tmp, 36 * (size_t)n));
@@ -806,25 +1003,19 @@ int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *
     const Params &p = h->p;
     if (cam) for (int q = 0; q < n; ++q) cam[q] = h->ref_cam[f0 + q];
     if (lmk) for (int q = 0; q < n; ++q) lmk[q] = h->ref_lmk[f0 + q];
-    if ((linpoint || meas) && n) {
-        std::vector<double> lin;
-        CHK(download(h, lin, p.lin, n_slots(h) * LIN_ROWS));
-        for (int q = 0; q < n; ++q) {
-            const size_t s = (size_t)h->ref2slot[f0 + q];
-            if (linpoint) for (int k = 0; k < 9; ++k) linpoint[(size_t)q * 9 + k] = lin[h_lin_at(s, ROW_X0 + k)];
-            if (meas) { meas[(size_t)q * 2] = lin[h_lin_at(s, ROW_Z)]; meas[(size_t)q * 2 + 1] = lin[h_lin_at(s, ROW_Z + 1)]; }
-        }
+    if ((linpoint || meas) && n) {                                  // gathered on the device: only the requested range moves
+        CHK(ensure_tmp(h, sizeof(double) * 11 * (size_t)n));
+        double *d_x0 = h->d_tmp, *d_z = h->d_tmp + 9 * (size_t)n;
+        hipLaunchKernelGGL(k_export_lin, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, p.cadj + f0, n, linpoint ? d_x0 : nullptr,
+                           meas ? d_z : nullptr);
+        HIPCHK(hipGetLastError());
+        if (linpoint) HIPCHK(hipMemcpyAsync(linpoint, d_x0, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        if (meas) HIPCHK(hipMemcpyAsync(meas, d_z, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
     }
     if ((eta || lam) && n) {
-        if ((size_t)n > h->ids_cap) {
-            if (h->d_ids) HIPCHK(hipFree(h->d_ids));
-            h->d_ids = nullptr; h->ids_cap = 0;
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_ids), sizeof(int) * (size_t)n));
-            h->ids_cap = n;
-        }
-        HIPCHK(hipMemcpyAsync(h->d_ids, h->ref2slot.data() + f0, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
         CHK(ensure_tmp(h, sizeof(double) * 90 * (size_t)n));
-        hipLaunchKernelGGL(k_export_factors, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, h->d_ids, n, h->d_tmp, h->d_tmp + 9 * (size_t)n);
+        hipLaunchKernelGGL(k_export_factors, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, p, p.cadj + f0, n, h->d_tmp, h->d_tmp + 9 * (size_t)n);
         HIPCHK(hipGetLastError());
         if (eta) HIPCHK(hipMemcpyAsync(eta, h->d_tmp, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
         if (lam) HIPCHK(hipMemcpyAsync(lam, h->d_tmp + 9 * (size_t)n, sizeof(double) * 81 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
@@ -833,23 +1024,43 @@ int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *
     return GBP_OK;
 }
 
+// the range [f0, f0+n) of the reference's factor order, gathered on the device (cadj = reference id -> slot)
+static int relin_range(gbp_ba *h, int32_t f0, int32_t n, int32_t *iters, double *eta_damping, double *adaptive_var, uint8_t *robust_flag)
+{
+    const Params &p = h->p;
+    if (!n) return GBP_OK;
+    const size_t N = (size_t)n;
+    CHK(ensure_tmp(h, N * (sizeof(double) + sizeof(int)) + N + 16));
+    double *d_av = h->d_tmp;
+    int *d_it = reinterpret_cast<int *>(h->d_tmp + N);
+    unsigned char *d_fl = reinterpret_cast<unsigned char *>(d_it + N);
+    hipLaunchKernelGGL(k_export_relin, dim3(grid_for(N)), dim3(BLOCK), 0, h->stream, p, p.cadj + f0, n, d_it, d_fl,
+                       adaptive_var ? d_av : nullptr);
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> fl(N);
+    if (iters) HIPCHK(hipMemcpyAsync(iters, d_it, N * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (adaptive_var) HIPCHK(hipMemcpyAsync(adaptive_var, d_av, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(fl.data(), d_fl, N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t q = 0; q < N; ++q) {
+        if (eta_damping) eta_damping[q] = (fl[q] & 1) ? p.eta_damping : 0.0;
+        if (robust_flag) robust_flag[q] = (uint8_t)((fl[q] >> 1) & 1);
+    }
+    return GBP_OK;
+}
+
 int gbp_ba_get_relin_state(gbp_ba_t *h, int32_t *iters, double *eta_damping, double *adaptive_var, uint8_t *robust_flag)
 {
     ENTER(h);
-    const Params &p = h->p;
-    std::vector<int32_t> st;
-    CHK(download(h, st, p.state, n_slots(h)));
-    std::vector<double> lin;
-    if (adaptive_var && p.loss != GBP_LOSS_NONE) CHK(download(h, lin, p.lin, n_slots(h) * LIN_ROWS));
-    for (int r = 0; r < p.F; ++r) {
-        const size_t slot = (size_t)h->ref2slot[r];
-        const int s = st[slot];
-        if (iters) iters[r] = s >> STATE_SHIFT;
-        if (eta_damping) eta_damping[r] = (s & 1) ? p.eta_damping : 0.0;
-        if (robust_flag) robust_flag[r] = (uint8_t)((s >> 1) & 1);
-        if (adaptive_var) adaptive_var[r] = p.loss != GBP_LOSS_NONE ? lin[h_lin_at(slot, ROW_AVAR)] : p.sigma2;
-    }
-    return GBP_OK;
+    return relin_range(h, 0, h->p.F, iters, eta_damping, adaptive_var, robust_flag);
+}
+
+int gbp_ba_get_relin_state_range(gbp_ba_t *h, int32_t f0, int32_t n, int32_t *iters, double *eta_damping, double *adaptive_var,
+                                 uint8_t *robust_flag)
+{
+    ENTER(h);
+    CHK(check_range(h, f0, n));
+    return relin_range(h, f0, n, iters, eta_damping, adaptive_var, robust_flag);
 }
 
 int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters)
@@ -857,19 +1068,50 @@ int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters)
     ENTER(h);
     if (!iters) return fail(GBP_EINVAL, "null argument");
     const Params &p = h->p;
-    std::vector<int32_t> st;
-    CHK(download(h, st, p.state, n_slots(h)));
-    for (int r = 0; r < p.F; ++r) {
-        int32_t &s = st[(size_t)h->ref2slot[r]];
-        s = (int32_t)(((uint32_t)iters[r] << STATE_SHIFT) | ((uint32_t)s & ((1u << STATE_SHIFT) - 1u)));
-    }
-    CHK(upload(h, p.state, st));
+    for (int r = 0; r < p.F; ++r)
+        if (iters[r] < 0 || iters[r] > ITERS_MAX) return fail(GBP_EINVAL, "iters_since_relin[%d] = %d outside [0, %d]", r, iters[r], ITERS_MAX);
+    if (!p.F) return GBP_OK;
+    CHK(ensure_tmp(h, sizeof(int) * (size_t)p.F));
+    int *d_it = reinterpret_cast<int *>(h->d_tmp);
+    HIPCHK(hipMemcpyAsync(d_it, iters, sizeof(int) * (size_t)p.F, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_import_iters, dim3(grid_for((size_t)p.F)), dim3(BLOCK), 0, h->stream, p, p.cadj, p.F, d_it);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));       // `iters` is the caller's
+    return GBP_OK;
+}
+
+int gbp_ba_count_relinearising(gbp_ba_t *h, int64_t *count)
+{
+    ENTER(h);
+    if (!count) return fail(GBP_EINVAL, "null argument");
+    *count = 0;
+    if (!h->p.T) return GBP_OK;
+    HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_count_relin, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, h->d_count);
+    HIPCHK(hipGetLastError());
+    int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *count = v;
+    return GBP_OK;
+}
+
+int gbp_ba_get_relin_counts(gbp_ba_t *h, int32_t *counts, int32_t n)
+{
+    ENTER(h);
+    if (n < 0 || (n && !counts)) return fail(GBP_EINVAL, "bad argument");
+    if (n > RELIN_RING / 2 || n > h->sweep_count)
+        return fail(GBP_EINVAL, "only the last min(%d, sweeps run = %ld) sweeps are kept", RELIN_RING / 2, h->sweep_count);
+    std::vector<int32_t> ring;
+    CHK(download(h, ring, h->d_relin_ring, (size_t)RELIN_RING));
+    for (int i = 0; i < n; ++i) counts[i] = ring[(size_t)((h->sweep_count - n + i) % RELIN_RING)];
     return GBP_OK;
 }
 
 int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
 {
     ENTER(h);
+    if (value < 0 || value > ITERS_MAX) return fail(GBP_EINVAL, "iters_since_relin %d outside [0, %d]", value, ITERS_MAX);
     const int n = h->p.T * WTILE;
     if (n) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p.state, n, value);
     HIPCHK(hipGetLastError());
@@ -1081,6 +1323,50 @@ int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches,
     if (kernel_name) *kernel_name = h->dominant;
     h->ev_used = 0;
     return GBP_OK;
+}
+
+int gbp_ba_get_kernel_times(gbp_ba_t *h, double *ms, int32_t cap, int32_t *n_launches)
+{
+    ENTER(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int32_t n = (int32_t)(h->ev_used / 2);
+    if (n_launches) *n_launches = n;
+    for (int32_t i = 0; i < n && i < cap && ms; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, h->ev[2 * (size_t)i], h->ev[2 * (size_t)i + 1]));
+        ms[i] = t;
+    }
+    return GBP_OK;
+}
+
+int gbp_ba_eval_fn(const double *K4, int32_t n, const double *x9, double *h2, double *J18, double *hproj2, int32_t device)
+{
+    if (!K4 || n < 0 || (n && !x9)) return fail(GBP_EINVAL, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GBP_ENODEV, "no HIP device visible: libgbp_hip.so has no CPU path");
+    if (device < 0 || device >= ndev) return fail(GBP_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    if (!n) return GBP_OK;
+    HIPCHK(hipSetDevice(device));
+    double *d = nullptr;
+    const size_t N = (size_t)n;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * N * (9 + 2 + 18 + 2)));
+    double *d_x = d, *d_h = d + 9 * N, *d_J = d_h + 2 * N, *d_hp = d_J + 18 * N;
+    hipError_t e = hipMemcpy(d_x, x9, sizeof(double) * 9 * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_eval_fn, dim3(grid_for(N)), dim3(BLOCK), 0, nullptr, Intrinsics{K4[0], K4[1], K4[2], K4[3]}, n, d_x, d_h, d_J, d_hp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && h2) e = hipMemcpy(h2, d_h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && J18) e = hipMemcpy(J18, d_J, sizeof(double) * 18 * N, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && hproj2) e = hipMemcpy(hproj2, d_hp, sizeof(double) * 2 * N, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GBP_EHIP, "gbp_ba_eval_fn: %s", hipGetErrorString(e));
+    return GBP_OK;
+}
+
+int gbp_ba_fused_max_cams(void)
+{
+    return fused_max_cams();
 }
 
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks)

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
             const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, ceC, clC,
                                                  [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
                                                  clL, eC, eL, WC, VL, MCn, MLn);
+            count_relin(p, relin);
             int sslot = slot;
             asm volatile("" : "+v"(sslot));             // store addresses are recomputed here, not kept alive (and spilled) through the maths
             if (relin) {
@@ -305,11 +306,25 @@ inline int fused_upload(FusedPlan &pl, T **dst, const T *src, size_t n, hipStrea
     return 0;
 }
 
+inline size_t fused_shmem(int C)
+{
+    const int acc_doubles = C * 27;
+    return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES) + 2);
+}
+
+// most cameras whose table + the per-wave scratch fit the LDS (the plan falls back to the general sweep above it)
+inline int fused_max_cams()
+{
+    int c = 0;
+    while (fused_shmem(c + 1) <= (size_t)LDS_BYTES) ++c;
+    return c;
+}
+
 // Workgroup tile ranges + per-workgroup camera tables; `big` = landmarks larger than a tile.
 inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
 {
     const int acc_doubles = p.C * 27;
-    const size_t shmem = sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES) + 2);
+    const size_t shmem = fused_shmem(p.C);
     if (shmem > (size_t)LDS_BYTES || p.F == 0 || p.C == 0 || p.T == 0) return 0;      // general sweep instead
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     std::vector<int32_t> blk((size_t)pl.n_blocks + 1);
@@ -336,7 +351,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 
 // returns 0 or a hipError_t value
 inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int local_relin, double *partial, hipStream_t stream,
-                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false)
 {
     Params p = p0;
     p.robustify = robustify; p.local_relin = local_relin;
@@ -348,7 +363,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles, pl.d_blk); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
-    if (pl.n_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
+    if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
     const size_t red_shmem = sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27);
     hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(BLOCK), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);
     return (int)hipGetLastError();

@@ -66,6 +66,7 @@ struct Params {
     const int *cptr, *cadj;
     double *cstage;               // general sweep: [F][27] camera messages in camera-major (reference) order, or NULL
     const int *cpos;              // slot -> row of cstage
+    int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
 };
 
 // element (slot, row) of a tile block: rows are stored in PAIRS, [row/2][lane][row%2], so that a lane owns 16 contiguous
@@ -77,6 +78,7 @@ GBP_DEV size_t msg_at(int slot, int row) { return (((size_t)(slot >> 6) * (MSG_R
 // state word: iters_since_relin << 12 | rank << 2 | robust << 1 | damped.  "rank" (10 bits) is constant per
 // factor: its index among the same-camera factors of its tile (fused sweep); every kernel carries it along.
 constexpr int STATE_SHIFT = 12;
+constexpr int ITERS_MAX = (1 << (31 - STATE_SHIFT)) - 1;     // iters_since_relin saturates here (524 287)
 constexpr unsigned STATE_RANK_MASK = 0x3ffu;
 GBP_DEV int state_iters(int st) { return st >> STATE_SHIFT; }
 GBP_DEV int state_rank(int st) { return (st >> 2) & (int)STATE_RANK_MASK; }
@@ -114,7 +116,10 @@ GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double 
             damped = false;
             relin = true;
         } else {
-            iters += 1;
+            // saturating: the counter shares the int32 state word (20 bits); only `>= min_linear` and `== num_undamped`
+            // are ever tested, and both thresholds are far below the cap (checked at create), so a converged factor that
+            // never relinearises behaves like the reference's unbounded Python int for ever
+            iters = min(iters + 1, ITERS_MAX);
         }
         if (iters == p.num_undamped) damped = true;      // gbp.py:50-51 (equality, not >=)
     }
@@ -179,6 +184,14 @@ GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2],
 #pragma unroll
     for (int i = 0; i < 3; ++i) eL[i] = eLn[i];
     return relin;
+}
+
+// ba.py:96-99 counts the factors with iters_since_relin == 0 after every sweep; the sweep kernels add their own count
+// into a per-sweep counter instead (one atomic per wave, none in a sweep where nobody relinearises).
+GBP_DEV void count_relin(const Params &p, bool relin)
+{
+    const unsigned long long rb = __ballot(relin);
+    if (p.relin_slot && rb != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)rb) - 1) atomicAdd(p.relin_slot, __popcll(rb));
 }
 
 // The dense messages of a slot (for the belief sums of the general path and the parity views): the precisions are
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC,
                                              [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
                                              lamL, eC, eL, WC, VL, MCn, MLn);
+        count_relin(p, relin);
         if (relin) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
@@ -570,6 +584,86 @@ __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *_
     }
 }
 
+// linearisation point / measurement of a list of slots (Factor.linpoint gbp.py:231, Factor.measurement gbp.py:233)
+__global__ __launch_bounds__(BLOCK) void k_export_lin(Params p, const int *__restrict__ slots, int n, double *__restrict__ x0_out,
+                                                      double *__restrict__ z_out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slots[i];
+    if (x0_out) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x0_out[(size_t)i * 9 + k] = p.lin[lin_at(slot, ROW_X0 + k)];
+    }
+    if (z_out) { z_out[(size_t)i * 2] = p.lin[lin_at(slot, ROW_Z)]; z_out[(size_t)i * 2 + 1] = p.lin[lin_at(slot, ROW_Z + 1)]; }
+}
+
+// relinearisation / robust state of a list of slots (gbp.py:242-249): iters_since_relin, flags (bit 0 damped, bit 1 robust),
+// adaptive variance
+__global__ __launch_bounds__(BLOCK) void k_export_relin(Params p, const int *__restrict__ slots, int n, int *__restrict__ iters,
+                                                        unsigned char *__restrict__ flags, double *__restrict__ avar)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slots[i], st = p.state[slot];
+    if (iters) iters[i] = state_iters(st);
+    if (flags) flags[i] = (unsigned char)(st & 3);
+    if (avar) avar[i] = p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+}
+
+// iters_since_relin of a list of slots (ba.py:91-93 per factor), clamped to the counter's range
+__global__ __launch_bounds__(BLOCK) void k_import_iters(Params p, const int *__restrict__ slots, int n, const int *__restrict__ iters)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int slot = slots[i];
+    const int v = min(max(iters[i], 0), ITERS_MAX);
+    p.state[slot] = (int)(((unsigned)v << STATE_SHIFT) | ((unsigned)p.state[slot] & ((1u << STATE_SHIFT) - 1u)));
+}
+
+// number of factors whose iters_since_relin is 0 (the loop of ba.py:96-99), one atomic per workgroup
+__global__ __launch_bounds__(BLOCK) void k_count_relin(Params p, int *__restrict__ out)
+{
+    __shared__ int red[BLOCK / 64];
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    int cam, lmk;
+    const bool hit = slot < p.T * WTILE && slot_info(p, slot, cam, lmk) && state_iters(p.state[slot]) == 0;
+    const unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) s += red[w];
+        if (s) atomicAdd(out, s);
+    }
+}
+
+// meas_fn / jac_fn of the reprojection factor at n free-standing points (reprojection.py:12-44): the unit the parity
+// tests pin against fixture G1 -- the same `linearise` every sweep kernel inlines
+__global__ __launch_bounds__(BLOCK) void k_eval_fn(Intrinsics K, int n, const double *__restrict__ x, double *__restrict__ h_out,
+                                                   double *__restrict__ J_out, double *__restrict__ hproj_out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double x9[9], Jc[2][6], Jl[2][3], h[2], hp[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x9[k] = x[(size_t)i * 9 + k];
+    linearise(x9, K, Jc, Jl, h);
+    project(x9, K, hp);
+    if (h_out) { h_out[(size_t)i * 2] = h[0]; h_out[(size_t)i * 2 + 1] = h[1]; }
+    if (hproj_out) { hproj_out[(size_t)i * 2] = hp[0]; hproj_out[(size_t)i * 2 + 1] = hp[1]; }
+    if (J_out) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) J_out[(size_t)i * 18 + r * 9 + k] = Jc[r][k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) J_out[(size_t)i * 18 + r * 9 + 6 + k] = Jl[r][k];
+        }
+    }
+}
+
 // dense messages of a list of slots for the parity views (Factor.messages gbp.py:222): eta 6 | Lambda 21 packed | eta 3 | Lambda 6 packed
 __global__ __launch_bounds__(BLOCK) void k_export_messages(Params p, const int *__restrict__ slots, int n, double *__restrict__ out)
 {
@@ -633,7 +727,7 @@ __global__ __launch_bounds__(BLOCK) void k_weaken_priors(Params p, double factor
 __global__ __launch_bounds__(BLOCK) void k_fill_iters(int *__restrict__ state, int n, int iters)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) state[i] = (int)(((unsigned)iters << STATE_SHIFT) | ((unsigned)state[i] & ((1u << STATE_SHIFT) - 1u)));
+    if (i < n) state[i] = (int)(((unsigned)min(max(iters, 0), ITERS_MAX) << STATE_SHIFT) | ((unsigned)state[i] & ((1u << STATE_SHIFT) - 1u)));
 }
 
 }  // namespace gbp

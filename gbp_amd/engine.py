@@ -14,6 +14,17 @@ from . import _capi
 from ._capi import check, dptr, iptr, bptr, f64, i32
 
 
+def eval_fn(K4, x9, device=0):
+    """meas_fn / jac_fn of the reprojection factor on the device (gbp_ba_eval_fn): (h (n,2), J (n,2,9), h_proj (n,2))."""
+    lib = _capi.load()
+    K = f64(np.asarray(K4, dtype=np.float64).reshape(-1), (4,))
+    x = f64(x9).reshape(-1, 9)
+    n = x.shape[0]
+    h, J, hp = np.empty((n, 2)), np.empty((n, 2, 9)), np.empty((n, 2))
+    check(lib.gbp_ba_eval_fn(dptr(K), n, dptr(x), dptr(h), dptr(J), dptr(hp), int(device)))
+    return h, J, hp
+
+
 class BAEngine:
     def __init__(self, K, cam_means, lmk_means, meas, cam_idx, lmk_idx, *, gauss_noise_std=2.0, loss=None,
                  Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8, eta_damping=0.4,
@@ -117,6 +128,47 @@ class BAEngine:
     def shard_end(self, gathered_ptr, n_ranks):
         check(self._lib.gbp_ba_shard_end(self._h, ct.c_void_p(gathered_ptr), int(n_ranks)))
 
+    # ---- in-library sharded loop (include/gbp_ba.h: gbp_ba_iterate_sharded) ---------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id made on one rank; every rank of the job passes the same bytes to comm_init_rccl."""
+        lib = _capi.load()
+        buf = ct.create_string_buffer(_capi.COMM_ID_BYTES)
+        check(lib.gbp_ba_comm_unique_id(buf, _capi.torch_rccl_path()))
+        return buf.raw
+
+    def comm_init_rccl(self, unique_id, rank, n_ranks, always_exchange=False):
+        if len(unique_id) != _capi.COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        check(self._lib.gbp_ba_comm_init_rccl(self._h, ct.c_char_p(bytes(unique_id)), int(rank), int(n_ranks),
+                                              _capi.XCH_ALWAYS if always_exchange else 0, _capi.torch_rccl_path()))
+
+    def set_exchange(self, fn, rank, n_ranks, always_exchange=False):
+        """fn(send_ptr, recv_ptr, count, stream_ptr) -> 0: a Python all-gather of the camera partial sums (tests, MPI)."""
+        if fn is None:
+            self._xch_cb = None
+            check(self._lib.gbp_ba_set_exchange(self._h, None, None, int(rank), int(n_ranks), 0))
+            return
+        def tramp(ctx, send, recv, count, stream):
+            try:
+                return int(fn(send, recv, int(count), stream) or 0)
+            except Exception:                      # nothing may propagate through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._xch_cb = _capi.EXCHANGE_FN(tramp)      # kept alive with the engine
+        check(self._lib.gbp_ba_set_exchange(self._h, ct.cast(self._xch_cb, ct.c_void_p), None, int(rank), int(n_ranks),
+                                            _capi.XCH_ALWAYS if always_exchange else 0))
+
+    def comm_destroy(self):
+        check(self._lib.gbp_ba_comm_destroy(self._h))
+
+    def iterate_sharded(self, n, robustify=True, local_relin=True):
+        check(self._lib.gbp_ba_iterate_sharded(self._h, int(n), int(bool(robustify)), int(bool(local_relin))))
+
+    def update_beliefs_sharded(self):
+        check(self._lib.gbp_ba_update_beliefs_sharded(self._h))
+
     # ---- diagnostics (gbp_ba.py:61-69, gbp.py:36-44) ---------------------------------------
     def are(self):
         v = ct.c_double()
@@ -177,6 +229,24 @@ class BAEngine:
         check(self._lib.gbp_ba_get_relin_state(self._h, iptr(it), dptr(d), dptr(av), bptr(rb)))
         return dict(iters_since_relin=it, eta_damping=d, adaptive_var=av, robust_flag=rb)
 
+    def relin_state_range(self, f0, n):
+        it, d = np.empty(n, np.int32), np.empty(n)
+        av, rb = np.empty(n), np.empty(n, np.uint8)
+        check(self._lib.gbp_ba_get_relin_state_range(self._h, int(f0), int(n), iptr(it), dptr(d), dptr(av), bptr(rb)))
+        return dict(iters_since_relin=it, eta_damping=d, adaptive_var=av, robust_flag=rb)
+
+    def count_relinearising(self):
+        """Number of factors with iters_since_relin == 0 (the loop of ba.py:96-99), reduced on the device."""
+        v = ct.c_int64()
+        check(self._lib.gbp_ba_count_relinearising(self._h, ct.byref(v)))
+        return v.value
+
+    def relin_counts(self, n):
+        """Factors that relinearised in each of the last n sweeps (oldest first)."""
+        out = np.empty(int(n), np.int32)
+        check(self._lib.gbp_ba_get_relin_counts(self._h, iptr(out), int(n)))
+        return out
+
     def set_iters_since_relin(self, v):
         if np.isscalar(v):
             check(self._lib.gbp_ba_fill_iters_since_relin(self._h, int(v)))
@@ -221,6 +291,14 @@ class BAEngine:
         ms, n, name = ct.c_double(), ct.c_int32(), ct.c_char_p()
         check(self._lib.gbp_ba_get_kernel_timing(self._h, ct.byref(ms), ct.byref(n), ct.byref(name)))
         return ms.value, n.value, (name.value or b'').decode()
+
+    def kernel_times(self):
+        """Milliseconds of every bracketed launch since set_kernel_timing, in order (call before kernel_timing())."""
+        n = ct.c_int32()
+        check(self._lib.gbp_ba_get_kernel_times(self._h, None, 0, ct.byref(n)))
+        out = np.empty(n.value)
+        check(self._lib.gbp_ba_get_kernel_times(self._h, dptr(out), n.value, ct.byref(n)))
+        return out
 
     def info(self):
         a, b, c = ct.c_int32(), ct.c_int32(), ct.c_int32()

@@ -11,9 +11,11 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI):
   * diagnostics (ARE / energy) need one 2-double all-reduce; generate_priors_var needs one MAX
     all-reduce over the per-camera factor maxima at set-up.
 
-The HIP work goes through the C ABI (gbp_ba_shard_begin / gbp_ba_shard_end); torch only provides the
-exchange buffers, the stream and the collective.  `engine_factory` lets the CPU tests run the very
-same host logic over gloo with a test double for the engine.
+On the GPU the whole loop runs inside libgbp_hip.so (gbp_ba_iterate_sharded: per sweep local kernels -> camera partial
+sums -> RCCL all-gather on the engine's stream -> rank-ordered sum; no host round trip per sweep): the communicator is the
+library's own, made from a 128-byte id that rank 0 creates and torch.distributed broadcasts.  torch.distributed is only the
+side channel (id, the two set-up / diagnostic reductions, barriers).  `engine_factory` lets the CPU tests run the same host
+logic over gloo with a test double for the engine; that path drives gbp_ba_shard_begin / _end-style calls from Python.
 """
 from __future__ import annotations
 
@@ -60,6 +62,19 @@ class _HipShard:
         self.stream = torch.cuda.Stream(self.device)
         self.engine.set_stream(self.stream.cuda_stream)
 
+    def init_comm(self, dist, always_exchange=False):
+        """The exchange of the in-library loop.  Real process groups: the library's own RCCL communicator (rank 0 makes the
+        id, the process group carries it to the others).  A `dist` object that brings its own `device_exchange(rank, send_ptr,
+        recv_ptr, count, stream_ptr)` (the thread-rank test double; an MPI build would do the same) is plugged in as the
+        exchange function instead."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if hasattr(dist, 'device_exchange'):
+            self.engine.set_exchange(lambda s, r, n, st: dist.device_exchange(rank, s, r, n, st), rank, world, always_exchange)
+            return
+        ids = [self.engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        self.engine.comm_init_rccl(ids[0], rank, world, always_exchange)
+
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
 
@@ -82,7 +97,8 @@ class _HipShard:
 class ShardedBA:
     """BAFactorGraph surface (gbp_ba.py:12-69) over `world` ranks; every rank calls every method."""
 
-    def __init__(self, problem: BAProblem, device=0, fused=True, engine_factory=None, dist=None, **cfg):
+    def __init__(self, problem: BAProblem, device=0, fused=True, engine_factory=None, dist=None, library_loop=True,
+                 always_exchange=False, **cfg):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -99,6 +115,10 @@ class ShardedBA:
         n = self.C * self.shard.partial_doubles
         self._partial = self.shard.new_buffer(n)
         self._gathered = self.shard.new_buffer(n * self.world)
+        self.library_loop = False
+        if hasattr(self.shard, 'init_comm') and library_loop:
+            self.shard.init_comm(dist, always_exchange)
+            self.library_loop = True
 
     # ---- set-up ---------------------------------------------------------------------------
     def generate_priors_var(self, weaker_factor=100.0):
@@ -123,16 +143,22 @@ class ShardedBA:
             self.dist.all_gather_into_tensor(self._gathered, self._partial)
 
     def update_all_beliefs(self):
+        if self.library_loop:
+            return self.engine.update_beliefs_sharded()
         self.shard.begin(self._partial, False, False, False)
         self._exchange()
         self.shard.end(self._gathered, self.world)
 
     def synchronous_iteration(self, local_relin=True, robustify=False):
+        if self.library_loop:
+            return self.engine.iterate_sharded(1, robustify, local_relin)
         self.shard.begin(self._partial, True, robustify, local_relin)
         self._exchange()
         self.shard.end(self._gathered, self.world)
 
     def iterate(self, n, robustify=True, local_relin=True):
+        if self.library_loop:
+            return self.engine.iterate_sharded(n, robustify, local_relin)
         for _ in range(int(n)):
             self.synchronous_iteration(local_relin=local_relin, robustify=robustify)
 
@@ -167,6 +193,30 @@ class ShardedBA:
 
     def sync(self):
         self.shard.sync()
+
+    def save_state(self):
+        return self.engine.save_state()
+
+    def load_state(self, blob):
+        self.engine.load_state(blob)
+
+    def kernel_times(self):
+        return self.engine.kernel_times()
+
+    def relin_counts(self, n):
+        """Factors that relinearised in each of the last n sweeps, summed over the ranks."""
+        c = self.engine.relin_counts(n).astype(np.int64)
+        with self._ctx():
+            t = self.shard.to_tensor(c)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.shard.sync()
+        return t.cpu().numpy()
+
+    def close(self):
+        if self.library_loop:
+            self.engine.comm_destroy()
+        if hasattr(self.engine, 'close'):
+            self.engine.close()
 
     def set_kernel_timing(self, on):
         self.engine.set_kernel_timing(on)

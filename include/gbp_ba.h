@@ -105,8 +105,24 @@ int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *
                        int32_t *cam, int32_t *lmk, double *meas);                                         /* Factor.factor/.linpoint/.adj_vIDs gbp.py:230-233 */
 int gbp_ba_get_relin_state(gbp_ba_t *h, int32_t *iters_since_relin, double *eta_damping,
                            double *adaptive_var, uint8_t *robust_flag);                                   /* gbp.py:242-249 */
+int gbp_ba_get_relin_state_range(gbp_ba_t *h, int32_t f0, int32_t n, int32_t *iters_since_relin, double *eta_damping,
+                                 double *adaptive_var, uint8_t *robust_flag);                             /* the same for factors [f0, f0+n) only */
 int gbp_ba_set_iters_since_relin(gbp_ba_t *h, const int32_t *iters);                                      /* ba.py:91-93 (per factor) */
 int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value);                                            /* ba.py:91-93 (all factors) */
+
+/* "Num factors relinearising" of ba.py:96-99 without reading F state words back: the number of factors whose
+ * iters_since_relin is 0 now (count_relinearising), and the numbers of factors that relinearised in each of the last n
+ * sweeps, oldest first (get_relin_counts; n <= 512 and <= sweeps run; the sweep kernels count on the device).
+ * iters_since_relin saturates at 524 287 (the reference's Python int is unbounded; only >= min_linear_iters and
+ * == num_undamped_iters are ever tested, gbp.py:50,72). */
+int gbp_ba_count_relinearising(gbp_ba_t *h, int64_t *count);
+int gbp_ba_get_relin_counts(gbp_ba_t *h, int32_t *counts, int32_t n);
+
+/* meas_fn / jac_fn of the reprojection factor at n free-standing 9-vectors x = (t, w, y), evaluated by the device code
+ * every sweep kernel inlines (gbp/factors/reprojection.py:12-44, utils/derivatives.py:36-50, utils/lie_algebra.py:32-42):
+ * h2[n*2] from the linearisation routine, J18[n*2*9] row-major, hproj2[n*2] from the projection-only routine used by
+ * the robust loss and the residual diagnostics.  Any output may be NULL.  No handle: K4 = fx fy cx cy. */
+int gbp_ba_eval_fn(const double *K4, int32_t n, const double *x9, double *h2, double *J18, double *hproj2, int32_t device);
 
 /* landmark-sharded multi-GPU sweep (no reference counterpart).  Each rank owns a
  * landmark range and its factors, cameras are replicated.  begin = (if with_messages) robustify /
@@ -115,6 +131,26 @@ int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value);                  
 int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, int32_t local_relin, double *partial_dev);
 int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks);
 #define GBP_CAM_PARTIAL_DOUBLES 27
+
+/* The same sweep with the loop and the camera exchange INSIDE the library (no host round trip per sweep): per iteration
+ * local kernels -> camera partial sums -> exchange -> rank-ordered sum + prior + 6x6 solve, all on the handle's stream.
+ * The exchange is an all-gather of C*27 doubles per rank:
+ *   - gbp_ba_comm_init_rccl: an RCCL communicator owned by the handle (librccl is dlopen()ed on first use; rccl_path NULL =
+ *     the copy already mapped in the process, else the system one).  gbp_ba_comm_unique_id on rank 0 makes the 128-byte
+ *     id every rank passes in (carry it over any side channel: MPI, torch.distributed, a file);
+ *   - gbp_ba_set_exchange: a caller-supplied function (MPI, peer-to-peer copies, a test double).  It must leave
+ *     recv_dev[r*count .. (r+1)*count) = rank r's send_dev for every r, ordered after the work already on hip_stream and
+ *     before anything enqueued on it afterwards, and return 0.
+ * With n_ranks == 1 nothing is exchanged (the path equals gbp_ba_iterate) unless flags has GBP_XCH_ALWAYS. */
+typedef int (*gbp_exchange_fn)(void *ctx, const double *send_dev, double *recv_dev, uint64_t count, void *hip_stream);
+#define GBP_COMM_ID_BYTES 128
+#define GBP_XCH_ALWAYS 1
+int gbp_ba_comm_unique_id(void *id128, const char *rccl_path);
+int gbp_ba_comm_init_rccl(gbp_ba_t *h, const void *id128, int32_t rank, int32_t n_ranks, int32_t flags, const char *rccl_path);
+int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank, int32_t n_ranks, int32_t flags);
+int gbp_ba_comm_destroy(gbp_ba_t *h);
+int gbp_ba_iterate_sharded(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin);   /* n x synchronous_iteration gbp.py:86-92 */
+int gbp_ba_update_beliefs_sharded(gbp_ba_t *h);                                                     /* update_all_beliefs gbp.py:56-58 */
 
 /* streaming export of all means for a viewer (the reference's viewer thread reads node.mu of every variable per frame,
  * vis/ba_vis.py:35-55): snapshot = taken in stream order, copied to a pinned host mirror on a copy stream while the
@@ -141,7 +177,9 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes);
  * brackets only every n-th launch (two event records per sweep are not free: ~6 us of a 125 us sweep) */
 int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
 int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);
+int gbp_ba_get_kernel_times(gbp_ba_t *h, double *ms, int32_t cap, int32_t *n_launches);   /* each bracketed launch, in order; call BEFORE get_kernel_timing (which resets) */
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);
+int gbp_ba_fused_max_cams(void);    /* most cameras the fused sweep takes (camera table + wave scratch in 160 KB of LDS); above it the general sweep runs */
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,42 @@ def g1(ref):
     save('G1_reproj_fn', x=xs, K=K, h=h, J=J)
 
 
+def g1b(ref):
+    """Edge cases of meas_fn / jac_fn (reprojection.py:12-44, derivatives.py:36-45, lie_algebra.py:32-42): rotation norms
+    from below the reference's 3*eps identity branch to many turns, axis-aligned and random axes, depths just above the
+    0.2 m floor.  Stored with each point: its rotation norm (the reference's own accuracy is ~eps/theta below 1e-3)."""
+    from gbp.factors import reprojection
+    from utils import lie_algebra
+    rng = np.random.default_rng(4321)
+    K = np.array([[517.306408, 0., 318.64304], [0., 516.469215, 255.313989], [0., 0., 1.]])
+    norms = [1e-16, 5e-16, 7e-16, 1e-12, 1e-8, 1e-6, 1e-4, 0.05, np.pi - 1e-6, np.pi, np.pi + 0.5, 2 * np.pi - 1e-9,
+             2 * np.pi + 0.3, 40.0, 1e3]
+    xs, th = [], []
+    for nrm in norms:
+        axes = [np.eye(3)[i] * sgn for i in range(3) for sgn in (1.0, -1.0)]
+        while len(axes) < 14:
+            a = rng.normal(size=3)
+            axes.append(a / np.linalg.norm(a))
+        for k, a in enumerate(axes):
+            w = a * nrm
+            R = lie_algebra.so3exp(w)
+            for _ in range(1000):
+                y = rng.uniform(-2, 2, 3)
+                depth = rng.uniform(0.2, 0.22) if k % 2 else rng.uniform(0.5, 6.0)
+                pc = np.array([rng.uniform(-0.4, 0.4) * depth, rng.uniform(-0.3, 0.3) * depth, depth])   # inside the image
+                t = pc - R @ y
+                x = np.concatenate([t, w, y])
+                if (lie_algebra.so3exp(x[3:6]) @ x[6:9] + x[0:3])[2] > 0.19:
+                    break
+            xs.append(x)
+            th.append(nrm)
+    xs = np.array(xs)
+    with np.errstate(all='ignore'):
+        h = np.array([reprojection.meas_fn(x, K) for x in xs])
+        J = np.array([reprojection.jac_fn(x, K) for x in xs])
+    save('G1b_reproj_fn_edge', x=xs, K=K, h=h, J=J, theta=np.array(th))
+
+
 def g2_g3(ref):
     from gbp import gbp_ba
     from utils import read_balfile
@@ -212,7 +248,7 @@ def g9(ref):
          meas=prob.meas, cam_idx=prob.cam_idx, lmk_idx=prob.lmk_idx, **out)
 
 
-ALL = dict(G1=g1, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
+ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

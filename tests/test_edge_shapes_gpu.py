@@ -1,0 +1,121 @@
+"""Deterministic graphs at the exact boundaries of the engine's plans (the fuzz only meets them by chance):
+the last camera count whose table fits the LDS / the first that does not (fused <-> general sweep), a landmark that fills
+a 64-slot tile exactly / one factor more (chunk tiles + k_lmk_belief_list), 24 / 25 landmarks in a tile."""
+import numpy as np
+import pytest
+
+from conftest import rel_err_rows
+from gbp_amd.synthetic import BAProblem, make_synthetic
+
+pytestmark = pytest.mark.gpu
+
+BELIEF_TOL = 1e-6
+
+
+def run_pair(oracle_mod, prob, n_sweeps=14, **kw):
+    from gbp_amd.engine import BAEngine
+    o = oracle_mod.OracleBA.from_problem(prob, threads=8)
+    e = BAEngine.from_problem(prob, **kw)
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+        oracle_mod.replay_ba(g, n_sweeps)
+    gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs()))
+    assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
+    return gap, o, e
+
+
+def test_camera_count_at_the_lds_boundary(oracle_mod):
+    from gbp_amd import _capi
+    cmax = _capi.load().gbp_ba_fused_max_cams()
+    assert 256 <= cmax <= 758                       # 160 KB / 216 B per camera, minus the per-wave scratch
+    for C, fused in ((cmax, True), (cmax + 1, False)):
+        prob = make_synthetic(n_cams=C, n_lmks=700, obs_per_lmk=6, seed=21)
+        gap, o, e = run_pair(oracle_mod, prob)
+        assert e.info()['fused'] == fused, (C, e.info())
+        assert gap < BELIEF_TOL, (C, gap)
+
+
+def with_landmarks(p, degrees, seed=5):
+    """p plus one landmark per entry of `degrees`, seen by that many cameras (points near the origin are in front of
+    and inside the image of every camera of the generator's shell)."""
+    from gbp_amd.synthetic import rodrigues
+    rng = np.random.default_rng(seed)
+    R = rodrigues(p.cam_means[:, 3:6])
+    lm, me, ci, li = [p.lmk_means], [p.meas], [p.cam_idx], [p.lmk_idx]
+    for j, deg in enumerate(degrees):
+        pt = rng.uniform(-0.3, 0.3, 3)
+        cams = np.sort(rng.permutation(p.n_cams)[:deg]).astype(np.int32)
+        pc = np.einsum('cij,j->ci', R[cams], pt) + p.cam_means[cams, 0:3]
+        assert (pc[:, 2] > 0.5).all()
+        uv = np.stack([p.K[0] * pc[:, 0] / pc[:, 2] + p.K[2], p.K[1] * pc[:, 1] / pc[:, 2] + p.K[3]], axis=1)
+        lm.append((pt + rng.normal(scale=0.05, size=3))[None]); me.append(uv + rng.normal(scale=1.0, size=uv.shape))
+        ci.append(cams); li.append(np.full(deg, p.n_lmks + j, np.int32))
+    # keep the file camera-major like the generator's output
+    cam_idx, lmk_idx, meas = np.concatenate(ci), np.concatenate(li), np.concatenate(me)
+    order = np.argsort(cam_idx, kind='stable')
+    return BAProblem(K=p.K, cam_means=p.cam_means, lmk_means=np.concatenate(lm), meas=meas[order],
+                     cam_idx=cam_idx[order].astype(np.int32), lmk_idx=lmk_idx[order].astype(np.int32))
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_landmark_degree_64_and_65(oracle_mod, fused):
+    """63 / 64 fill one tile (whole landmark owned by the tile), 65 / 128 / 129 become chunk tiles whose landmark belief
+    comes from k_lmk_belief_list."""
+    base = make_synthetic(n_cams=140, n_lmks=60, obs_per_lmk=5, seed=31)
+    prob = with_landmarks(base, [64, 65, 63, 128, 129, 2])
+    gap, o, e = run_pair(oracle_mod, prob, fused=fused)
+    assert gap < BELIEF_TOL, gap
+    for a, b in zip(e.messages(), o.messages()):
+        assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+
+
+@pytest.mark.parametrize('n_lmks,n_tiles', [(24, 1), (25, 2), (48, 2), (49, 3)])
+def test_24_and_25_landmarks_per_tile(oracle_mod, n_lmks, n_tiles):
+    prob = make_synthetic(n_cams=12, n_lmks=n_lmks, obs_per_lmk=2, seed=41)
+    gap, o, e = run_pair(oracle_mod, prob)
+    assert e.info()['n_tiles'] == n_tiles
+    assert gap < BELIEF_TOL, gap
+
+
+@pytest.mark.parametrize('obs,n_lmks,n_tiles', [(4, 16, 1), (4, 17, 2), (3, 21, 1), (3, 22, 2)])
+def test_tile_filled_to_the_last_slot(oracle_mod, obs, n_lmks, n_tiles):
+    """16 x 4 = 64 slots used exactly; 21 x 3 = 63 (the 22nd landmark does not fit the one free slot)."""
+    prob = make_synthetic(n_cams=12, n_lmks=n_lmks, obs_per_lmk=obs, seed=43)
+    gap, o, e = run_pair(oracle_mod, prob)
+    assert e.info()['n_tiles'] == n_tiles
+    assert gap < BELIEF_TOL, gap
+
+
+def test_relinearisation_counters(oracle_mod):
+    """Device-side counts of ba.py:96-99 against the per-factor state, and the saturating iters_since_relin."""
+    from gbp_amd import _capi
+    from gbp_amd.engine import BAEngine
+    prob = make_synthetic(n_cams=10, n_lmks=300, obs_per_lmk=4, seed=51)
+    e = BAEngine.from_problem(prob)
+    e.generate_priors_var(50.0)
+    e.update_all_beliefs()
+    seen = []
+    for i in range(20):
+        e.iterate(1)
+        st = e.relin_state()
+        seen.append(int((st['iters_since_relin'] == 0).sum()))
+        assert e.count_relinearising() == seen[-1]
+    assert np.array_equal(e.relin_counts(20), seen)
+    assert max(seen) > 0
+    r = e.relin_state_range(100, 50)
+    assert np.array_equal(r['iters_since_relin'], st['iters_since_relin'][100:150])
+    assert np.array_equal(r['eta_damping'], st['eta_damping'][100:150])
+    f = e.factors(100, 50, dense=False)
+    full = e.factors(dense=False)
+    assert np.array_equal(f['linpoint'], full['linpoint'][100:150]) and np.array_equal(f['z'], full['z'][100:150])
+    # saturation: the counter stops at 2^19 - 1 instead of running into the sign bit of the state word
+    top = (1 << 19) - 1
+    e.set_iters_since_relin(top - 1)
+    e.iterate(3, local_relin=True)
+    st = e.relin_state()['iters_since_relin']
+    assert ((st == top) | (st < 8)).all()           # saturated, or relinearised meanwhile
+    with pytest.raises(_capi.GbpError):
+        e.set_iters_since_relin(top + 1)
+    with pytest.raises(_capi.GbpError):
+        e.set_iters_since_relin(np.full(e.F, -1, np.int32))

@@ -296,8 +296,10 @@ def test_error_paths(eng_mod):
 
 
 def test_sharded_driver_single_rank_nccl(eng_mod, oracle_mod):
-    """gbp_amd.sharded on the real engine with RCCL, world_size 1 (the GPU box has one device): the shard_begin /
-    all_gather / shard_end path must reproduce gbp_ba_iterate exactly."""
+    """gbp_amd.sharded on the real engine with RCCL, world_size 1 (the GPU box has one device): the in-library loop
+    (gbp_ba_iterate_sharded: sweep -> reduce -> ncclAllGather on the library's own communicator -> rank-ordered finish,
+    forced to exchange although there is one rank) and the Python-driven shard_begin / all_gather_into_tensor / shard_end
+    path must both reproduce gbp_ba_iterate exactly."""
     import socket
     import torch
     import torch.distributed as dist
@@ -308,19 +310,22 @@ def test_sharded_driver_single_rank_nccl(eng_mod, oracle_mod):
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         p = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
-        g = ShardedBA(p, device=0)
         e = eng_mod.BAEngine.from_problem(p)
-        for x in (g, e):
+        graphs = [ShardedBA(p, device=0, always_exchange=True), ShardedBA(p, device=0, library_loop=False), ShardedBA(p, device=0)]
+        assert graphs[0].library_loop and not graphs[1].library_loop
+        for x in graphs + [e]:
             x.generate_priors_var(50.0)
             x.update_all_beliefs()
             oracle_mod.replay_ba(x, 12)
-        g.sync()
-        ce, cl = g.camera_beliefs()
-        _, le, ll = g.local_landmark_beliefs()
         ref = e.beliefs()
-        assert np.array_equal(ce, ref[0]) and np.array_equal(cl, ref[1])
-        assert np.array_equal(le, ref[2]) and np.array_equal(ll, ref[3])
-        assert g.are() == pytest.approx(e.are(), rel=1e-12)
+        for g in graphs:
+            g.sync()
+            ce, cl = g.camera_beliefs()
+            _, le, ll = g.local_landmark_beliefs()
+            assert np.array_equal(ce, ref[0]) and np.array_equal(cl, ref[1])
+            assert np.array_equal(le, ref[2]) and np.array_equal(ll, ref[3])
+            assert g.are() == pytest.approx(e.are(), rel=1e-12)
+            g.close()
     finally:
         dist.destroy_process_group()
 

@@ -46,6 +46,17 @@ def test_g1_meas_and_jacobian(oracle_mod):
         assert np.allclose(J2, J, rtol=1e-10, atol=1e-12 * np.abs(J).max())
 
 
+def test_g1b_edge_rotations(oracle_mod):
+    """Rotation norms from below the 3*eps identity branch to many turns, depths at the 0.2 m floor: the restatement
+    follows the reference's formula operation by operation, so it stays within rounding of it everywhere."""
+    g = golden('G1b_reproj_fn_edge')
+    K4 = np.array([g['K'][0, 0], g['K'][1, 1], g['K'][0, 2], g['K'][1, 2]])
+    for x, h, J in zip(g['x'], g['h'], g['J']):
+        h2, J2 = oracle_mod.fn_eval(x, K4)
+        assert np.allclose(h2, h, rtol=1e-11, atol=1e-9)
+        assert np.abs(J2 - J).max() <= 1e-12 * np.abs(J).max()
+
+
 def test_g2_reader_and_initial_factors(oracle_mod):
     g = golden('G2_init_factors_vsmall')
     p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))

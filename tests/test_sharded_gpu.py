@@ -1,8 +1,9 @@
 """The landmark-sharded driver with the REAL HIP engine at world sizes 2 and 3 on ONE GPU: every "rank" is a thread with
 its own BAEngine (own stream) on device 0, and the collectives are a lock-step test double of torch.distributed (shared
 slots + a barrier; gathers are concatenated in rank order exactly like all_gather_into_tensor).  This exercises what the
-1-GPU box cannot do with RCCL: gbp_ba_shard_begin / gbp_ba_shard_end with n_ranks > 1 on real kernels (fused and general
-sweeps), the partition, the MAX all-reduce of generate_priors_var and the globally normalised diagnostics."""
+1-GPU box cannot do with RCCL: the in-library loop gbp_ba_iterate_sharded with n_ranks > 1 on real kernels (fused and
+general sweeps) through a plugged-in exchange function, the Python-driven gbp_ba_shard_begin / _end path, the partition,
+the MAX all-reduce of generate_priors_var and the globally normalised diagnostics."""
 import os
 import threading
 
@@ -48,6 +49,23 @@ class LockstepDist:
         self.shared.barrier.wait()                           # everybody has copied before anyone overwrites
         return parts
 
+    def device_exchange(self, rank, send_ptr, recv_ptr, count, stream_ptr):
+        """gbp_exchange_fn of the in-library loop (gbp_ba_iterate_sharded): all-gather of `count` doubles per rank between
+        raw device pointers, lock-step through host slots."""
+        import ctypes as ct
+        hip = ct.CDLL('libamdhip64.so')                      # the runtime the process already holds
+        hip.hipStreamSynchronize.argtypes = [ct.c_void_p]
+        hip.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
+        assert hip.hipStreamSynchronize(ct.c_void_p(stream_ptr)) == 0          # this rank's producer kernels
+        mine = np.empty(count)
+        assert hip.hipMemcpy(mine.ctypes.data_as(ct.c_void_p), ct.c_void_p(send_ptr), count * 8, 2) == 0      # D2H
+        self.shared.slots[rank] = mine
+        self.shared.barrier.wait()
+        allp = np.concatenate(self.shared.slots)
+        assert hip.hipMemcpy(ct.c_void_p(recv_ptr), allp.ctypes.data_as(ct.c_void_p), allp.size * 8, 1) == 0   # H2D
+        self.shared.barrier.wait()                           # everybody has copied before anyone overwrites
+        return 0
+
     def all_gather_into_tensor(self, out, inp):
         import torch
         out.copy_(torch.cat(self._exchange(inp)))
@@ -58,7 +76,7 @@ class LockstepDist:
         t.copy_(parts.max(dim=0).values if op == 'max' else parts.sum(dim=0))
 
 
-def run_world(problem, world, fused, n_sweeps, oracle_mod):
+def run_world(problem, world, fused, n_sweeps, oracle_mod, library_loop=True):
     from gbp_amd.sharded import ShardedBA
     shared = LockstepWorld(world)
     out, errors = [None] * world, []
@@ -67,7 +85,8 @@ def run_world(problem, world, fused, n_sweeps, oracle_mod):
         try:
             import torch
             torch.cuda.set_device(0)
-            g = ShardedBA(problem, device=0, fused=fused, dist=LockstepDist(shared, r))
+            g = ShardedBA(problem, device=0, fused=fused, dist=LockstepDist(shared, r), library_loop=library_loop)
+            assert g.library_loop == library_loop
             g.generate_priors_var(50.0)
             g.update_all_beliefs()
             ares, energies = oracle_mod.replay_ba(g, n_sweeps, diagnostics=True)
@@ -88,8 +107,8 @@ def run_world(problem, world, fused, n_sweeps, oracle_mod):
     return out
 
 
-@pytest.mark.parametrize('world,fused', [(2, True), (3, True), (2, False)])
-def test_sharded_engine_matches_single_engine(oracle_mod, world, fused):
+@pytest.mark.parametrize('world,fused,library_loop', [(2, True, True), (3, True, True), (2, False, True), (2, True, False)])
+def test_sharded_engine_matches_single_engine(oracle_mod, world, fused, library_loop):
     from gbp_amd.engine import BAEngine
     p = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
     ref = BAEngine.from_problem(p, fused=fused)
@@ -97,7 +116,7 @@ def test_sharded_engine_matches_single_engine(oracle_mod, world, fused):
     ref.update_all_beliefs()
     ares, energies = oracle_mod.replay_ba(ref, 14, diagnostics=True)
     rce, rcl, rle, rll = ref.beliefs()
-    ranks = run_world(p, world, fused, 14, oracle_mod)
+    ranks = run_world(p, world, fused, 14, oracle_mod, library_loop)
     assert sum(r['F'] for r in ranks) == p.n_factors
     lo = 0
     for r in ranks:

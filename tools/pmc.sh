@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
-timeout 200 rocprofv3 --pmc $CTR -f csv -d $OUT -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+timeout 200 rocprofv3 --pmc $CTR -f csv -d $OUT -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --single-batch "$@" > $OUT/bench.log 2>&1
 python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: [0, 0.0])

@@ -10,8 +10,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o run -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline "$@" > $OUT/bench_stats.log 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/fetch -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_fetch.log 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/write -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_write.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o run -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --single-batch "$@" > $OUT/bench_stats.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/fetch -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --single-batch "$@" > $OUT/bench_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/write -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --single-batch "$@" > $OUT/bench_write.log 2>&1
 find $OUT -name "*.csv" | xargs ls -la
 python tools/summarize_profile.py $OUT
