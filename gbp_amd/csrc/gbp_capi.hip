@@ -262,8 +262,9 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
     if (finished) *finished = false;
     if (with_messages) {
         const int slot = (int)(h->sweep_count % RELIN_RING);
-        if (slot % (RELIN_RING / 2) == 0) HIPCHK(hipMemsetAsync(h->d_relin_ring + slot, 0, sizeof(int) * (RELIN_RING / 2), h->stream));
-        h->p.relin_slot = h->d_relin_ring + slot;
+        if (slot % (RELIN_RING / 2) == 0)
+            HIPCHK(hipMemsetAsync(h->d_relin_ring + (size_t)slot * RELIN_LANES, 0, sizeof(int) * (RELIN_RING / 2) * RELIN_LANES, h->stream));
+        h->p.relin_slot = h->d_relin_ring + (size_t)slot * RELIN_LANES;
         h->sweep_count++;
     }
     if (with_messages && h->fused.enabled) {
@@ -533,7 +534,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     p.cptr = cptr; p.cadj = cadj;
 
     CHK(dev_alloc(h, &h->d_partial, (size_t)std::max(C, 1) * 27));
-    CHK(dev_alloc(h, &h->d_relin_ring, (size_t)RELIN_RING));
+    CHK(dev_alloc(h, &h->d_relin_ring, (size_t)RELIN_RING * RELIN_LANES));
     CHK(dev_alloc(h, &h->d_count, 1));
     CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(std::max<size_t>(S, 1))));
 
@@ -1103,8 +1104,13 @@ int gbp_ba_get_relin_counts(gbp_ba_t *h, int32_t *counts, int32_t n)
     if (n > RELIN_RING / 2 || n > h->sweep_count)
         return fail(GBP_EINVAL, "only the last min(%d, sweeps run = %ld) sweeps are kept", RELIN_RING / 2, h->sweep_count);
     std::vector<int32_t> ring;
-    CHK(download(h, ring, h->d_relin_ring, (size_t)RELIN_RING));
-    for (int i = 0; i < n; ++i) counts[i] = ring[(size_t)((h->sweep_count - n + i) % RELIN_RING)];
+    CHK(download(h, ring, h->d_relin_ring, (size_t)RELIN_RING * RELIN_LANES));
+    for (int i = 0; i < n; ++i) {
+        const int32_t *w = &ring[(size_t)((h->sweep_count - n + i) % RELIN_RING) * RELIN_LANES];
+        int32_t s = 0;
+        for (int k = 0; k < RELIN_LANES; ++k) s += w[k];
+        counts[i] = s;
+    }
     return GBP_OK;
 }
 

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     // tile's landmark messages and priors wait in the wave's LDS scratch, which the next tile overwrites only afterwards.
     bool pend = false;
     int q_t = 0, q_l0 = 0, q_nl = 0;
+    int n_relin = 0;                                      // factors of this wave's tiles that relinearised (wave-uniform)
 
     for (;;) {
         int ti = 0;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
             const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, ceC, clC,
                                                  [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
                                                  clL, eC, eL, WC, VL, MCn, MLn);
-            count_relin(p, relin);
+            n_relin += relin_in_wave(relin);
             int sslot = slot;
             asm volatile("" : "+v"(sslot));             // store addresses are recomputed here, not kept alive (and spilled) through the maths
             if (relin) {
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         pend = true; q_t = t; q_l0 = l0; q_nl = nl;
     }
+    if (lane == 0) relin_add(p, n_relin);
     __syncthreads();
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
