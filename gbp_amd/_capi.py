@@ -15,6 +15,7 @@ _bp = ct.POINTER(ct.c_uint8)
 
 LOSS = {None: 0, 'None': 0, 'none': 0, 'huber': 1, 'constant': 2}
 FLAG_NO_FUSED = 1
+FLAG_DEVICE_INPUT = 2
 CAM_PARTIAL_DOUBLES = 27
 COMM_ID_BYTES = 128
 XCH_ALWAYS = 1
@@ -110,6 +111,7 @@ SIGNATURES = {
     'gbp_lin_get_means': (ct.c_int, [ct.c_void_p, _dp]),
     'gbp_lin_get_messages': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
     'gbp_ba_fused_max_cams': (ct.c_int, []),
+    'gbp_ba_check_layout': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32)]),
     'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
 }
 

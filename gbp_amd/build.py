@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgbp_hip.so')
-SOURCES = ['gbp_capi.hip', 'gbp_lin_capi.hip']
-DEPS = ['gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_kernels.hpp', 'gbp_fused.hpp', 'gbp_math.hpp', 'gbp_balio.hpp',
+SOURCES = ['gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip']
+DEPS = ['gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip', 'gbp_build.hpp', 'gbp_kernels.hpp', 'gbp_fused.hpp', 'gbp_math.hpp', 'gbp_balio.hpp',
         os.path.join('..', '..', 'include', 'gbp_ba.h'), os.path.join('..', '..', 'include', 'gbp_lin.h')]
 
 

@@ -1,0 +1,226 @@
+// gbp_build.hpp -- device side of gbp_ba_create: the reference's create_ba_graph (gbp/gbp_ba.py:97-150) as kernels.
+//
+// The reference walks all observations once per camera (an O(C F) Python loop, gbp_ba.py:128-130) to put the factors in
+// camera-major order, and generate_priors_var (gbp_ba.py:20-34) walks every variable's adjacent factors.  Here everything
+// that is F-sized happens on the GPU:
+//   1. k_check_ids            ids inside [0,C) x [0,L)?  camera ids already non-decreasing (every shipped file is)?
+//   2. sort_pairs             stable by camera      -> reference factor r = file row ref_file[r]       (skipped when sorted)
+//      k_lower_bounds         camera CSR offsets cptr
+//   3. sort_pairs             stable by landmark    -> landmark-major list lm2ref (adj_factors order), offsets lptr
+//   4. tile packing           a next-fit walk over the L landmark degrees (64 slots / 24 landmarks per tile, landmarks above 64
+//                             factors cut into chunk tiles).  The walk is sequential in L, not F: it runs on the host over the
+//                             downloaded lptr (0.4 MB at 100k landmarks) and uploads the tile table (T x 16 B)
+//   5. k_build_tiles          one wave per tile: every slot finds its factor, writes x0 | z | variance, meta, state (with the
+//                             factor's rank among the same-camera factors of its tile) and both directions of the
+//                             reference-id <-> slot map
+//   6. k_init_vars            landmark records (mean, slot range) and camera records (mean)
+// and the priors (gbp_ba.py:20-34) are a per-slot max of Lambda_f (k_factor_lambda_max), a segmented max per landmark over its
+// contiguous slots, a per-camera max through the camera's adj_factors list, and k_prior_scalars -- no F-sized array crosses PCIe
+// after the observations themselves went up.
+#pragma once
+#include "gbp_kernels.hpp"
+
+namespace gbp {
+
+size_t sort_pairs_tmp_bytes(size_t n, int bits);
+int sort_pairs(void *tmp, size_t tmp_bytes, const int *keys_in, int *keys_out, const int *vals_in, int *vals_out, size_t n, int bits,
+               hipStream_t stream);
+
+// flags[0]: an id outside its range; flags[1]: camera ids not sorted (a stable sort is needed)
+__global__ __launch_bounds__(BLOCK) void k_check_ids(const int *__restrict__ cam, const int *__restrict__ lmk, int F, int C, int L,
+                                                     int *__restrict__ flags)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= F) return;
+    const int c = cam[i], l = lmk[i];
+    if (c < 0 || c >= C || l < 0 || l >= L) flags[0] = 1;
+    if (i > 0 && cam[i - 1] > c) flags[1] = 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_iota(int *__restrict__ a, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gather_int(const int *__restrict__ src, const int *__restrict__ idx, int *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// ptr[v] = number of keys below v in the sorted list, v = 0 .. n_vals (CSR offsets of a sorted key list)
+__global__ __launch_bounds__(BLOCK) void k_lower_bounds(const int *__restrict__ keys, int n, int *__restrict__ ptr, int n_vals)
+{
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v > n_vals) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    ptr[v] = lo;
+}
+
+struct BuildArgs {
+    int4 *tiles;                          // in: {first landmark, landmarks owned, slots used, -}; out: .w = max rank
+    const int *lrow0, *lptr;              // per landmark: first slot; offsets into lm2ref
+    const int *lm2ref, *ref_cam, *ref_file;   // ref_file may be NULL (reference order == file order)
+    const double *cam_means, *lmk_means, *meas;
+    unsigned *meta;
+    int *ref2slot, *cpos;
+};
+
+// One wave per tile (create_ba_graph's per-factor part, gbp_ba.py:131-141: linpoint = concat(cam.mu, lmk.mu), measurement,
+// adaptive variance = sigma^2, iters_since_relin = 1 gbp.py:249).
+__global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
+{
+    const int lane = threadIdx.x & 63, t = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (t >= p.T) return;
+    const int4 td = a.tiles[t];
+    const int slot = t * WTILE + lane;
+    const bool active = lane < td.z;
+    int cam = -1 - lane, l = td.x, r = 0;       // inactive lanes: distinct negative "cameras" that match nobody
+    if (active) {
+        if (td.y > 0) {
+            int k = 0;
+            for (int i = 1; i < td.y; ++i) k += (a.lrow0[td.x + i] <= slot) ? 1 : 0;     // rows ascend with the landmark
+            l = td.x + k;
+        }
+        r = a.lm2ref[a.lptr[l] + (slot - a.lrow0[l])];
+        cam = a.ref_cam[r];
+    }
+    // rank among the same-camera factors of the tile, in slot order (the order of the LDS accumulation of the fused sweep)
+    int rank = 0;
+#pragma unroll 8
+    for (int i = 0; i < WTILE; ++i) {
+        const int ci = __shfl(cam, i, 64);
+        rank += (i < lane && ci == cam) ? 1 : 0;
+    }
+    int mr = active ? rank : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mr = max(mr, __shfl_down(mr, off, 64));
+    if (lane == 0) a.tiles[t].w = mr;
+    p.state[slot] = state_pack(1, active ? rank : 0, false, false);
+    a.meta[slot] = active ? (((unsigned)cam << META_LMK_BITS) | (unsigned)(td.y > 0 ? l - td.x : 0)) : 0u;
+    a.cpos[slot] = active ? r : 0;
+    if (!active) return;
+    a.ref2slot[r] = slot;
+    const int fi = a.ref_file ? a.ref_file[r] : r;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = a.cam_means[(size_t)cam * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.lin[lin_at(slot, ROW_X0 + 6 + k)] = a.lmk_means[(size_t)l * 3 + k];
+    p.lin[lin_at(slot, ROW_Z)] = a.meas[(size_t)fi * 2];
+    p.lin[lin_at(slot, ROW_Z + 1)] = a.meas[(size_t)fi * 2 + 1];
+    p.lin[lin_at(slot, ROW_AVAR)] = p.sigma2;                                            // gbp.py:242
+}
+
+// node.mu = initial estimate (gbp_ba.py:116,123); landmark records also carry their slot range
+__global__ __launch_bounds__(BLOCK) void k_init_vars(Params p, const double *__restrict__ cam_means, const double *__restrict__ lmk_means,
+                                                     const int *__restrict__ lrow0, const int *__restrict__ lrow1)
+{
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v < p.C) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p.cbel[(size_t)v * CAMREC + CAM_MU + k] = cam_means[(size_t)v * 6 + k];
+    } else if (v < p.C + p.L) {
+        const int l = v - p.C;
+        double *lr = p.lrec + (size_t)l * LREC;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lr[LR_MU + k] = lmk_means[(size_t)l * 3 + k];
+        *reinterpret_cast<int2 *>(lr + LR_ROWS) = make_int2(lrow0[l], lrow1[l]);
+    }
+}
+
+// Debug check of the layout the build produced (GBP_DEBUG_LAYOUT=1 and the tests): every used slot decodes to the camera and
+// landmark of the reference factor it holds, and the two maps invert each other.  err[0] = number of bad slots.
+__global__ __launch_bounds__(BLOCK) void k_check_layout(Params p, const int *__restrict__ ref_cam, const int *__restrict__ ref_lmk,
+                                                        int *__restrict__ err)
+{
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    int cam, lmk;
+    if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
+    const int r = p.cpos[slot];
+    if (r < 0 || r >= p.F || p.cadj[r] != slot || ref_cam[r] != cam || ref_lmk[r] != lmk || lmk < 0 || lmk >= p.L) atomicAdd(err, 1);
+}
+
+// ---- priors: generate_priors_var gbp_ba.py:20-34 ------------------------------------------------------------------------
+// max over a landmark's adjacent factors of max(Lambda_f): its slots are contiguous
+__global__ __launch_bounds__(BLOCK) void k_lmk_max(Params p, const double *__restrict__ fm, double *__restrict__ lmk_max)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l >= p.L) return;
+    const int2 rows = *reinterpret_cast<const int2 *>(p.lrec + (size_t)l * LREC + LR_ROWS);
+    double m = 0.0;                                     // max_factor_lam = 0.  gbp_ba.py:27
+    for (int s = rows.x; s < rows.y; ++s) m = fmax(m, fm[s]);
+    lmk_max[l] = m;
+}
+
+// one workgroup per camera: max over its adj_factors list (cadj = reference id -> slot)
+__global__ __launch_bounds__(BLOCK) void k_cam_max(Params p, const double *__restrict__ fm, double *__restrict__ cam_max)
+{
+    __shared__ double red[BLOCK / 64];
+    const int c = blockIdx.x;
+    double m = 0.0;
+    for (int e = p.cptr[c] + threadIdx.x; e < p.cptr[c + 1]; e += BLOCK) m = fmax(m, fm[p.cadj[e]]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) m = fmax(m, red[w]);
+        cam_max[c] = m;
+    }
+}
+
+// prior Lambda = (lambda / w2) I, eta = Lambda mu   (gbp_ba.py:32-34; w2 = weaker_factor^2, 1 when the caller gives Lambda)
+__global__ __launch_bounds__(BLOCK) void k_prior_scalars(Params p, const double *__restrict__ cam_lambda, const double *__restrict__ lmk_lambda,
+                                                         double w2)
+{
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v < p.C) {
+        const double lam = cam_lambda[v] / w2;
+        double *pr = p.cprior + (size_t)v * 27;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) pr[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { pr[k] = lam * p.cbel[(size_t)v * CAMREC + CAM_MU + k]; pr[6 + Sym<6>::at(k, k)] = lam; }
+    } else if (v < p.C + p.L) {
+        const int l = v - p.C;
+        const double lam = lmk_lambda[l] / w2;
+        double *lr = p.lrec + (size_t)l * LREC;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lr[LR_PRIOR + k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lr[LR_PRIOR + k] = lam * lr[LR_MU + k]; lr[LR_PRIOR + 3 + Sym<3>::at(k, k)] = lam; }
+    }
+}
+
+// packed landmark priors (eta 3 | Lambda 6) into the landmark records
+__global__ __launch_bounds__(BLOCK) void k_scatter_lmk_priors(Params p, const double *__restrict__ pri)
+{
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < (size_t)p.L * 9) p.lrec[(i / 9) * LREC + LR_PRIOR + (i % 9)] = pri[i];
+}
+
+// order-independent 64-bit digest of the factor layout (reference id -> slot, camera, landmark): pins a state blob to its graph
+__global__ __launch_bounds__(BLOCK) void k_graph_hash(const int *__restrict__ ref2slot, const int *__restrict__ ref_cam,
+                                                      const int *__restrict__ ref_lmk, int F, unsigned long long *__restrict__ out)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long v = 0ull;
+    if (r < F) {
+        v = ((unsigned long long)(unsigned)r << 32) ^ (unsigned)ref2slot[r];
+        v = (v ^ (v >> 33)) * 0xff51afd7ed558ccdull;
+        v ^= ((unsigned long long)(unsigned)ref_cam[r] << 32) | (unsigned)ref_lmk[r];
+        v = (v ^ (v >> 33)) * 0xc4ceb9fe1a85ec53ull;
+        v ^= v >> 33;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+}  // namespace gbp

@@ -1,12 +1,13 @@
 // gbp_capi.hip -- host side of libgbp_hip.so: graph lay-out, launches and the C ABI of include/gbp_ba.h.
 //
-// No CPU compute path lives here: every sweep, belief update and diagnostic is a HIP kernel.  Host
-// code only (a) permutes the caller's arrays between the reference's factor order and the internal
-// landmark-major layout, (b) packs/unpacks symmetric matrices for the views, (c) does the one-off
-// per-variable max of generate_priors_var (gbp_ba.py:27-31) over factor maxima computed on device.
+// No CPU compute path lives here: every sweep, belief update and diagnostic is a HIP kernel, and so is the graph build
+// (gbp_build.hpp: ordering, slot assignment, initial linearisation points, prior maxima).  Host code only (a) walks the L
+// landmark degrees once to pack tiles, (b) packs/unpacks symmetric matrices for the views, (c) owns handles, streams and
+// the optional RCCL communicator.
 #include "../../include/gbp_ba.h"
 #include "gbp_kernels.hpp"
 #include "gbp_fused.hpp"
+#include "gbp_build.hpp"
 #include "gbp_balio.hpp"
 
 #include <rccl/rccl.h>      // types only: the library is dlopen()ed when a communicator is asked for (no link-time dependency)
@@ -66,13 +67,11 @@ struct gbp_ba {
     int device = 0;
     int flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    // host-side order maps
-    std::vector<int32_t> ref2slot;               // reference factor id -> slot (tile*64 + lane)
-    std::vector<int32_t> ref_cam, ref_lmk;       // per reference factor
-    std::vector<int32_t> h_cptr;                 // camera CSR offsets in reference order
-    std::vector<int32_t> h_lrow0, h_lrow1;       // per landmark: its slot range [row0, row1)
+    // order maps: on the device (built there, gbp_build.hpp); the host keeps only what is L- or C-sized
+    int *d_ref_cam = nullptr, *d_ref_lmk = nullptr;   // per reference factor (p.cadj = reference id -> slot, p.cpos = slot -> reference id)
     std::vector<int32_t> big_lmks;               // landmarks larger than a tile
     int *d_big = nullptr;                        // the same on the device (general sweep)
+    bool hash_ok = false; uint64_t hash = 0;     // digest of the layout (state blobs)
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -99,7 +98,8 @@ struct gbp_ba {
     // enters it, so the last RELIN_RING/2 sweeps are always readable
     int *d_relin_ring = nullptr;
     long sweep_count = 0;
-    int *d_count = nullptr;                      // scratch counter of gbp_ba_count_relinearising
+    int *d_count = nullptr;                      // scratch counter of gbp_ba_count_relinearising / gbp_ba_check_layout
+    double *d_varmax = nullptr;                  // C + L: per-variable max of Lambda_f, or the prior scalars on their way in
     // landmark-sharded sweep: the camera exchange (include/gbp_ba.h gbp_ba_set_exchange / gbp_ba_comm_init_rccl)
     gbp_exchange_fn xch_fn = nullptr;
     void *xch_ctx = nullptr;
@@ -223,27 +223,18 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
     return GBP_OK;
 }
 
-// camera-major staging of the general sweep, allocated on first use (F x 27 doubles + F ints)
+// camera-major staging of the general sweep, allocated on first use (F x 27 doubles; the slot -> row map cpos is made by the build)
 static int ensure_staging(gbp_ba *h)
 {
     if (h->p.cstage) return GBP_OK;
-    const size_t S = (size_t)h->p.T * WTILE;
-    std::vector<int32_t> cpos(std::max<size_t>(S, 1), 0);
-    for (size_t e = 0; e < h->ref2slot.size(); ++e) cpos[(size_t)h->ref2slot[e]] = (int32_t)e;     // cadj[e] = slot  <=>  cpos[slot] = e
-    int *d_cpos = nullptr;
-    CHK(dev_alloc(h, &d_cpos, cpos.size(), false));
-    CHK(upload(h, d_cpos, cpos));
     CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * CSTAGE_ROW));
     if (!h->big_lmks.empty() && !h->d_big) {
         CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
         CHK(upload(h, h->d_big, h->big_lmks));
     }
-    h->p.cpos = d_cpos;
     return GBP_OK;
 }
 
-// one synchronous_iteration's device work up to (and including) this rank's camera partial sums; with finish != 0 the
-// camera beliefs are completed as well (single GPU) and *finished tells the caller so
 static int launch_big_lmk_beliefs(gbp_ba *h, hipStream_t stream)
 {
     const int *list = h->fused.enabled ? h->fused.d_big : h->d_big;
@@ -381,9 +372,163 @@ void gbp_ba_destroy(gbp_ba_t *h)
     delete h;
 }
 
-static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
+extern "C++" {
+// host -> device copy of a caller array that is released at the end of create (or the caller's own device pointer)
+template <typename T>
+static int stage_input(gbp_ba *h, const T *src, size_t n, bool on_device, std::vector<void *> &scratch, const T **out)
+{
+    if (on_device || !n) { *out = src; return GBP_OK; }
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, n * sizeof(T)));
+    scratch.push_back(q);
+    HIPCHK(hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *out = static_cast<const T *>(q);
+    return GBP_OK;
+}
+
+template <typename T>
+static int scratch_alloc(std::vector<void *> &scratch, T **out, size_t n)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    scratch.push_back(q);
+    *out = static_cast<T *>(q);
+    return GBP_OK;
+}
+
+}  // extern "C++"
+
+static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &scratch, int n_cus)
 {
     const int C = d->n_cams, L = d->n_lmks, F = d->n_factors;
+    Params &p = h->p;
+    const bool dev_in = (d->flags & GBP_FLAG_DEVICE_INPUT) != 0;
+    const size_t Fz = (size_t)F;
+    const int *cam_idx = nullptr, *lmk_idx = nullptr;
+    const double *meas = nullptr, *cam_means = nullptr, *lmk_means = nullptr;
+    CHK(stage_input(h, d->cam_idx, Fz, dev_in, scratch, &cam_idx)); CHK(stage_input(h, d->lmk_idx, Fz, dev_in, scratch, &lmk_idx));
+    CHK(stage_input(h, d->meas, Fz * 2, dev_in, scratch, &meas));
+    CHK(stage_input(h, d->cam_means, (size_t)C * 6, dev_in, scratch, &cam_means));
+    CHK(stage_input(h, d->lmk_means, (size_t)L * 3, dev_in, scratch, &lmk_means));
+
+    // 1. ids in range?  already camera-major?
+    int *d_flags = nullptr;
+    CHK(scratch_alloc(scratch, &d_flags, 2));
+    HIPCHK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), h->stream));
+    if (F) hipLaunchKernelGGL(k_check_ids, dim3(grid_for(Fz)), dim3(BLOCK), 0, h->stream, cam_idx, lmk_idx, F, C, L, d_flags);
+    HIPCHK(hipGetLastError());
+    int flags[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (flags[0]) return fail(GBP_EINVAL, "an observation references a camera outside [0,%d) or a landmark outside [0,%d)", C, L);
+
+    // 2. reference order: camera-major, stable in file order (gbp_ba.py:128-130)
+    int *iota = nullptr, *ref_file = nullptr, *lm_key = nullptr, *lm2ref = nullptr, *lptr = nullptr, *cptr = nullptr, *cadj = nullptr, *cpos = nullptr;
+    CHK(dev_alloc(h, &h->d_ref_cam, std::max<size_t>(Fz, 1), false)); CHK(dev_alloc(h, &h->d_ref_lmk, std::max<size_t>(Fz, 1), false));
+    CHK(scratch_alloc(scratch, &iota, Fz)); CHK(scratch_alloc(scratch, &lm_key, Fz)); CHK(scratch_alloc(scratch, &lm2ref, Fz));
+    CHK(scratch_alloc(scratch, &lptr, (size_t)L + 1));
+    CHK(dev_alloc(h, &cptr, (size_t)C + 1)); CHK(dev_alloc(h, &cadj, std::max<size_t>(Fz, 1)));
+    int bits_c = 1, bits_l = 1;
+    while ((1 << bits_c) < C) ++bits_c;
+    while ((1 << bits_l) < L) ++bits_l;
+    void *sort_tmp = nullptr;
+    const size_t sort_bytes = F ? std::max(sort_pairs_tmp_bytes(Fz, bits_c), sort_pairs_tmp_bytes(Fz, bits_l)) : 0;
+    if (sort_bytes) { HIPCHK(hipMalloc(&sort_tmp, sort_bytes)); scratch.push_back(sort_tmp); }
+    if (F) hipLaunchKernelGGL(k_iota, dim3(grid_for(Fz)), dim3(BLOCK), 0, h->stream, iota, F);
+    const bool sorted = !flags[1];
+    if (F && !sorted) {
+        CHK(scratch_alloc(scratch, &ref_file, Fz));
+        HIPCHK((hipError_t)sort_pairs(sort_tmp, sort_bytes, cam_idx, h->d_ref_cam, iota, ref_file, Fz, bits_c, h->stream));
+        hipLaunchKernelGGL(k_gather_int, dim3(grid_for(Fz)), dim3(BLOCK), 0, h->stream, lmk_idx, ref_file, h->d_ref_lmk, F);
+    } else if (F) {
+        HIPCHK(hipMemcpyAsync(h->d_ref_cam, cam_idx, Fz * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ref_lmk, lmk_idx, Fz * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(k_lower_bounds, dim3(grid_for((size_t)C + 1)), dim3(BLOCK), 0, h->stream, h->d_ref_cam, F, cptr, C);
+    // 3. landmark-major, stable in reference id (= VariableNode.adj_factors order, gbp_ba.py:139)
+    if (F) HIPCHK((hipError_t)sort_pairs(sort_tmp, sort_bytes, h->d_ref_lmk, lm_key, iota, lm2ref, Fz, bits_l, h->stream));
+    hipLaunchKernelGGL(k_lower_bounds, dim3(grid_for((size_t)L + 1)), dim3(BLOCK), 0, h->stream, lm_key, F, lptr, L);
+    HIPCHK(hipGetLastError());
+
+    // 4. tiles: up to 64 slots / TILE_LMKS whole landmarks each; over-sized landmarks become chunk tiles (nl = 0).
+    //    A next-fit walk over the L degrees: sequential, but L-sized -- done here on the downloaded offsets.
+    std::vector<int32_t> h_lptr;
+    CHK(download(h, h_lptr, lptr, (size_t)L + 1));
+    std::vector<int4> tiles;
+    std::vector<int32_t> lrow0((size_t)std::max(L, 1), 0), lrow1((size_t)std::max(L, 1), 0);
+    {
+        int cur_l0 = 0, cur_nf = 0, cur_nl = 0;
+        auto flush = [&]() {
+            if (cur_nl > 0) tiles.push_back(make_int4(cur_l0, cur_nl, cur_nf, 0));
+            cur_nf = 0; cur_nl = 0;
+        };
+        for (int l = 0; l < L; ++l) {
+            const int deg = h_lptr[l + 1] - h_lptr[l];
+            if (deg > WTILE) {
+                flush();
+                lrow0[l] = (int32_t)(tiles.size() * WTILE);
+                for (int o = 0; o < deg; o += WTILE) tiles.push_back(make_int4(l, 0, std::min(WTILE, deg - o), 0));
+                lrow1[l] = lrow0[l] + deg;          // chunk tiles are full except the last: the slots are contiguous
+                h->big_lmks.push_back(l);
+                continue;
+            }
+            if (cur_nl > 0 && (cur_nf + deg > WTILE || cur_nl == TILE_LMKS)) flush();
+            if (cur_nl == 0) cur_l0 = l;
+            lrow0[l] = (int32_t)(tiles.size() * WTILE) + cur_nf; lrow1[l] = lrow0[l] + deg;
+            cur_nf += deg; cur_nl += 1;
+        }
+        flush();
+    }
+    const int T = (int)tiles.size();
+    const size_t S = std::max<size_t>((size_t)T * WTILE, 1);
+    p.T = T;
+
+    // 5. per-slot data
+    unsigned *d_meta = nullptr; int4 *d_tiles = nullptr; int *d_lrow0 = nullptr, *d_lrow1 = nullptr;
+    CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
+    CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
+    CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1), false));
+    CHK(scratch_alloc(scratch, &d_lrow0, (size_t)L)); CHK(scratch_alloc(scratch, &d_lrow1, (size_t)L));
+    CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
+    CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
+    if (T) HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)T * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    if (L) {
+        HIPCHK(hipMemcpyAsync(d_lrow0, lrow0.data(), (size_t)L * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d_lrow1, lrow1.data(), (size_t)L * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    p.meta = d_meta; p.tiles = d_tiles; p.cptr = cptr; p.cadj = cadj; p.cpos = cpos;
+    if (T) {
+        BuildArgs a{d_tiles, d_lrow0, lptr, lm2ref, h->d_ref_cam, ref_file, cam_means, lmk_means, meas, d_meta, cadj, cpos};
+        hipLaunchKernelGGL(k_build_tiles, dim3((T + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, h->stream, p, a);
+    }
+    // 6. variables
+    if (C + L) hipLaunchKernelGGL(k_init_vars, dim3(grid_for((size_t)C + L)), dim3(BLOCK), 0, h->stream, p, cam_means, lmk_means, d_lrow0, d_lrow1);
+    HIPCHK(hipGetLastError());
+
+    CHK(dev_alloc(h, &h->d_partial, (size_t)std::max(C, 1) * 27));
+    CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(S)));
+    CHK(dev_alloc(h, &h->d_relin_ring, (size_t)RELIN_RING * RELIN_LANES));
+    CHK(dev_alloc(h, &h->d_count, 2));
+    CHK(dev_alloc(h, &h->d_varmax, (size_t)std::max(C + L, 1), false));
+
+    if (getenv("GBP_DEBUG_LAYOUT")) {
+        int bad = 0;
+        CHK(gbp_ba_check_layout(h, &bad));
+        if (bad) return fail(GBP_ESTATE, "internal layout error: %d slots do not decode to their reference factor", bad);
+    }
+    if (!(h->flags & GBP_FLAG_NO_FUSED)) {
+        HIPCHK(hipStreamSynchronize(h->stream));            // tiles[].w (max rank) is written by k_build_tiles
+        int rc = fused_plan(h->fused, p, h->big_lmks, h->stream, n_cus);
+        if (rc < 0) return fail(GBP_EHIP, "building the fused sweep plan failed (%d)", rc);
+        if (h->fused.enabled) h->dominant = "k_sweep_fused";
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));                // the staged inputs are released by the caller
+    return GBP_OK;
+}
+
+static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
+{
+    const int C = d->n_cams;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(GBP_ENODEV, "no HIP device visible: libgbp_hip.so has no CPU path");
@@ -399,152 +544,21 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     h->flags = d->flags;
 
     Params &p = h->p;
-    p.F = F; p.L = L; p.C = C; p.T = 0;
+    p.F = d->n_factors; p.L = d->n_lmks; p.C = C; p.T = 0;
     p.K = Intrinsics{d->K[0], d->K[1], d->K[2], d->K[3]};
     p.sigma2 = d->gauss_noise_std * d->gauss_noise_std;
     p.nstds = d->nstds; p.beta = d->beta; p.eta_damping = d->eta_damping;
     p.num_undamped = d->num_undamped_iters; p.min_linear = d->min_linear_iters; p.loss = d->loss;
     p.robustify = 0; p.local_relin = 1;
-
-    // reference order: camera-major, stable in file order (gbp_ba.py:128-130)
-    h->h_cptr.assign((size_t)C + 1, 0);
-    for (int i = 0; i < F; ++i) {
-        if (d->cam_idx[i] < 0 || d->cam_idx[i] >= C || d->lmk_idx[i] < 0 || d->lmk_idx[i] >= L)
-            return fail(GBP_EINVAL, "observation %d references camera %d / landmark %d outside [0,%d) / [0,%d)",
-                        i, d->cam_idx[i], d->lmk_idx[i], C, L);
-        h->h_cptr[(size_t)d->cam_idx[i] + 1]++;
-    }
     if (d->num_undamped_iters > ITERS_MAX || d->min_linear_iters > ITERS_MAX)
         return fail(GBP_EINVAL, "num_undamped_iters / min_linear_iters above %d are not supported (iters_since_relin saturates there)", ITERS_MAX);
     if (C >= (1 << (32 - META_LMK_BITS))) return fail(GBP_EINVAL, "more than %d cameras are not supported", (1 << (32 - META_LMK_BITS)) - 1);
-    for (int c = 0; c < C; ++c) h->h_cptr[c + 1] += h->h_cptr[c];
-    std::vector<int32_t> ref_file((size_t)F);
-    {
-        std::vector<int32_t> cur(h->h_cptr.begin(), h->h_cptr.end() - 1);
-        for (int i = 0; i < F; ++i) ref_file[(size_t)cur[d->cam_idx[i]]++] = i;
-    }
-    h->ref_cam.resize(F); h->ref_lmk.resize(F);
-    for (int r = 0; r < F; ++r) { h->ref_cam[r] = d->cam_idx[ref_file[r]]; h->ref_lmk[r] = d->lmk_idx[ref_file[r]]; }
-    // landmark-major order, stable in reference id (= VariableNode.adj_factors order, gbp_ba.py:139)
-    std::vector<int32_t> lptr((size_t)L + 1, 0), lm2ref((size_t)F);
-    for (int r = 0; r < F; ++r) lptr[(size_t)h->ref_lmk[r] + 1]++;
-    for (int l = 0; l < L; ++l) lptr[l + 1] += lptr[l];
-    {
-        std::vector<int32_t> cur(lptr.begin(), lptr.end() - 1);
-        for (int r = 0; r < F; ++r) lm2ref[(size_t)cur[h->ref_lmk[r]]++] = r;
-    }
-    // tiles: up to 64 slots / TILE_LMKS whole landmarks each; over-sized landmarks become chunk tiles (nl = 0)
-    std::vector<int4> tiles;
-    h->h_lrow0.assign((size_t)L, 0); h->h_lrow1.assign((size_t)L, 0);
-    h->ref2slot.assign((size_t)F, -1);
-    std::vector<int32_t> slot2ref;
-    {
-        int cur_l0 = 0, cur_nf = 0, cur_nl = 0;
-        auto flush = [&]() {
-            if (cur_nl > 0) { tiles.push_back(make_int4(cur_l0, cur_nl, cur_nf, 0)); slot2ref.resize(tiles.size() * WTILE, -1); }
-            cur_nf = 0; cur_nl = 0;
-        };
-        for (int l = 0; l < L; ++l) {
-            const int deg = lptr[l + 1] - lptr[l];
-            if (deg > WTILE) {
-                flush();
-                h->h_lrow0[l] = (int32_t)(tiles.size() * WTILE);
-                for (int o = 0; o < deg; o += WTILE) {
-                    const int n = std::min(WTILE, deg - o);
-                    const int base = (int)tiles.size() * WTILE;
-                    tiles.push_back(make_int4(l, 0, n, 0));
-                    slot2ref.resize(tiles.size() * WTILE, -1);
-                    for (int j = 0; j < n; ++j) slot2ref[(size_t)base + j] = lm2ref[(size_t)lptr[l] + o + j];
-                }
-                h->h_lrow1[l] = h->h_lrow0[l] + deg;     // chunk tiles are full except the last: the slots are contiguous
-                h->big_lmks.push_back(l);
-                continue;
-            }
-            if (cur_nl > 0 && (cur_nf + deg > WTILE || cur_nl == TILE_LMKS)) flush();
-            if (cur_nl == 0) cur_l0 = l;
-            const int base = (int)tiles.size() * WTILE + cur_nf;
-            slot2ref.resize((tiles.size() + 1) * WTILE, -1);
-            for (int j = 0; j < deg; ++j) slot2ref[(size_t)base + j] = lm2ref[(size_t)lptr[l] + j];
-            h->h_lrow0[l] = base; h->h_lrow1[l] = base + deg;
-            cur_nf += deg; cur_nl += 1;
-        }
-        flush();
-    }
-    const int T = (int)tiles.size();
-    const size_t S = (size_t)T * WTILE;
-    slot2ref.resize(S, -1);
-    p.T = T;
 
-    std::vector<double> lin(std::max<size_t>(S, 1) * LIN_ROWS, 0.0);
-    std::vector<int32_t> state(std::max<size_t>(S, 1), 1 << STATE_SHIFT);           // iters_since_relin = 1  gbp.py:249
-    std::vector<uint32_t> meta(std::max<size_t>(S, 1), 0u);
-    std::vector<int32_t> stamp((size_t)std::max(C, 1), -1), count((size_t)std::max(C, 1), 0);
-    for (int t = 0; t < T; ++t) {
-        int4 &td = tiles[t];
-        int mr = 0;
-        for (int j = 0; j < td.z; ++j) {
-            const size_t s = (size_t)t * WTILE + j;
-            const int r = slot2ref[s], c = h->ref_cam[r], l = h->ref_lmk[r], fi = ref_file[r];
-            h->ref2slot[r] = (int32_t)s;
-            auto at = [&](int row) { return (((size_t)t * (LIN_ROWS / 2) + (row >> 1)) * WTILE + j) * 2 + (row & 1); };
-            for (int k = 0; k < 6; ++k) lin[at(ROW_X0 + k)] = d->cam_means[(size_t)c * 6 + k];     // linpoint = concat(cam.mu, lmk.mu) gbp_ba.py:136
-            for (int k = 0; k < 3; ++k) lin[at(ROW_X0 + 6 + k)] = d->lmk_means[(size_t)l * 3 + k];
-            lin[at(ROW_Z)] = d->meas[(size_t)fi * 2]; lin[at(ROW_Z + 1)] = d->meas[(size_t)fi * 2 + 1];
-            lin[at(ROW_AVAR)] = p.sigma2;                                                       // gbp.py:242
-            // rank among the same-camera factors of the tile (order of the LDS accumulation in the fused sweep)
-            if (stamp[c] != t) { stamp[c] = t; count[c] = 0; }
-            state[s] |= count[c] << 2;
-            mr = std::max(mr, count[c]);
-            count[c]++;
-            meta[s] = ((uint32_t)c << META_LMK_BITS) | (uint32_t)(td.y > 0 ? l - td.x : 0);
-        }
-        td.w = mr;
-    }
-    for (int t = 0; t < T; ++t)                       // layout self-check (cheap, set-up only)
-        for (int j = 0; j < tiles[t].z; ++j) {
-            const uint32_t m = meta[(size_t)t * WTILE + j];
-            const int c = (int)(m >> META_LMK_BITS), l = tiles[t].x + (int)(m & ((1u << META_LMK_BITS) - 1u));
-            const int r = slot2ref[(size_t)t * WTILE + j];
-            if (r < 0 || c != h->ref_cam[r] || l != h->ref_lmk[r] || l < 0 || l >= L)
-                return fail(GBP_ESTATE, "internal layout error at tile %d lane %d (cam %d lmk %d ref %d)", t, j, c, l, r);
-        }
-    unsigned *d_meta = nullptr; int4 *d_tiles = nullptr;
-    CHK(dev_alloc(h, &p.lin, std::max<size_t>(S, 1) * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, std::max<size_t>(S, 1) * MSG_ROWS));
-    CHK(dev_alloc(h, &p.state, std::max<size_t>(S, 1))); CHK(dev_alloc(h, &d_meta, std::max<size_t>(S, 1)));
-    CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1)));
-    CHK(upload(h, p.lin, lin)); CHK(upload(h, p.state, state)); CHK(upload(h, d_meta, meta));
-    if (T) CHK(upload(h, d_tiles, tiles));
-    p.meta = d_meta; p.tiles = d_tiles;
-
-    CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
-    CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
-    {
-        std::vector<double> lr((size_t)std::max(L, 1) * LREC, 0.0), cb((size_t)std::max(C, 1) * CAMREC, 0.0);
-        for (int l = 0; l < L; ++l) {
-            for (int k = 0; k < 3; ++k) lr[(size_t)l * LREC + LR_MU + k] = d->lmk_means[(size_t)l * 3 + k];   // node.mu = init gbp_ba.py:123
-            int32_t rows[2] = {h->h_lrow0[l], h->h_lrow1[l]};
-            memcpy(&lr[(size_t)l * LREC + LR_ROWS], rows, sizeof rows);
-        }
-        for (int c = 0; c < C; ++c) for (int k = 0; k < 6; ++k) cb[(size_t)c * CAMREC + CAM_MU + k] = d->cam_means[(size_t)c * 6 + k];
-        CHK(upload(h, p.lrec, lr)); CHK(upload(h, p.cbel, cb));
-    }
-    int *cptr = nullptr, *cadj = nullptr;
-    CHK(dev_alloc(h, &cptr, (size_t)C + 1)); CHK(dev_alloc(h, &cadj, (size_t)std::max(F, 1)));
-    CHK(upload(h, cptr, h->h_cptr)); CHK(upload(h, cadj, h->ref2slot));
-    p.cptr = cptr; p.cadj = cadj;
-
-    CHK(dev_alloc(h, &h->d_partial, (size_t)std::max(C, 1) * 27));
-    CHK(dev_alloc(h, &h->d_relin_ring, (size_t)RELIN_RING * RELIN_LANES));
-    CHK(dev_alloc(h, &h->d_count, 1));
-    CHK(dev_alloc(h, &h->d_red, 2 * (size_t)grid_for(std::max<size_t>(S, 1))));
-
-    if (!(h->flags & GBP_FLAG_NO_FUSED)) {
-        int rc = fused_plan(h->fused, p, h->big_lmks, h->stream, prop.multiProcessorCount);
-        if (rc < 0) return fail(GBP_EHIP, "building the fused sweep plan failed (%d)", rc);
-        if (h->fused.enabled) h->dominant = "k_sweep_fused";
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return GBP_OK;
+    std::vector<void *> scratch;                             // device buffers only the build needs
+    const int rc = build_graph(h, d, scratch, prop.multiProcessorCount);
+    (void)hipStreamSynchronize(h->stream);
+    for (void *q : scratch) (void)hipFree(q);
+    return rc;
 }
 
 int gbp_ba_create(gbp_ba_t **out, const gbp_ba_desc_t *d)
@@ -591,43 +605,28 @@ int gbp_ba_sync(gbp_ba_t *h)
 // ------------------------------------------------------------------------------- priors ---
 
 static inline size_t n_slots(const gbp_ba *h) { return std::max<size_t>((size_t)h->p.T * WTILE, 1); }
-static inline size_t h_lin_at(size_t slot, int row) { return (((slot >> 6) * (LIN_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
+
+// max over the adjacent factors of every variable of max(Lambda_f) (gbp_ba.py:27-31) into d_varmax = cameras | landmarks
+static int variable_lambda_max(gbp_ba *h)
+{
+    const Params &p = h->p;
+    const size_t S = n_slots(h);
+    CHK(ensure_tmp(h, sizeof(double) * S));
+    if (p.T) hipLaunchKernelGGL(k_factor_lambda_max, dim3(grid_for(S)), dim3(BLOCK), 0, h->stream, p, h->d_tmp);
+    if (p.C) hipLaunchKernelGGL(k_cam_max, dim3(p.C), dim3(BLOCK), 0, h->stream, p, h->d_tmp, h->d_varmax);
+    if (p.L) hipLaunchKernelGGL(k_lmk_max, dim3(grid_for((size_t)p.L)), dim3(BLOCK), 0, h->stream, p, h->d_tmp, h->d_varmax + p.C);
+    HIPCHK(hipGetLastError());
+    return GBP_OK;
+}
 
 int gbp_ba_factor_lambda_max(gbp_ba_t *h, double *cam_max, double *lmk_max)
 {
     ENTER(h);
     const Params &p = h->p;
-    const size_t S = n_slots(h);
-    CHK(ensure_tmp(h, sizeof(double) * S));
-    if (p.T) hipLaunchKernelGGL(k_factor_lambda_max, dim3(grid_for(S)), dim3(BLOCK), 0, h->stream, p, h->d_tmp);
-    HIPCHK(hipGetLastError());
-    std::vector<double> fm;
-    CHK(download(h, fm, h->d_tmp, p.T ? S : 0));
-    // max_factor_lam = 0.; max over adjacent factors (gbp_ba.py:27-31)
-    if (lmk_max)
-        for (int l = 0; l < p.L; ++l) {
-            double m = 0.0;
-            for (int s = h->h_lrow0[l]; s < h->h_lrow1[l]; ++s) m = std::max(m, fm[s]);
-            lmk_max[l] = m;
-        }
-    if (cam_max)
-        for (int c = 0; c < p.C; ++c) {
-            double m = 0.0;
-            for (int r = h->h_cptr[c]; r < h->h_cptr[c + 1]; ++r) m = std::max(m, fm[h->ref2slot[r]]);
-            cam_max[c] = m;
-        }
-    return GBP_OK;
-}
-
-// write landmark priors (packed eta 3 | Lambda 6 per landmark) into the landmark records, keeping the rest
-static int upload_lmk_priors(gbp_ba *h, const std::vector<double> &pri)
-{
-    const Params &p = h->p;
-    std::vector<double> lr;
-    CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
-    for (int l = 0; l < p.L; ++l)
-        for (int k = 0; k < 9; ++k) lr[(size_t)l * LREC + LR_PRIOR + k] = pri[(size_t)l * 9 + k];
-    CHK(upload(h, p.lrec, lr));
+    CHK(variable_lambda_max(h));
+    if (cam_max && p.C) HIPCHK(hipMemcpyAsync(cam_max, h->d_varmax, sizeof(double) * (size_t)p.C, hipMemcpyDeviceToHost, h->stream));
+    if (lmk_max && p.L) HIPCHK(hipMemcpyAsync(lmk_max, h->d_varmax + p.C, sizeof(double) * (size_t)p.L, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return GBP_OK;
 }
 
@@ -637,24 +636,12 @@ int gbp_ba_set_prior_scalars(gbp_ba_t *h, const double *cam_lambda, const double
     h->resid_ok = false;
     const Params &p = h->p;
     if (!cam_lambda || !lmk_lambda) return fail(GBP_EINVAL, "null argument");
-    std::vector<double> cb, lr;
-    CHK(download(h, cb, p.cbel, (size_t)std::max(p.C, 1) * CAMREC));
-    CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
-    std::vector<double> cp((size_t)std::max(p.C, 1) * 27, 0.0), lp((size_t)std::max(p.L, 1) * 9, 0.0);
-    for (int c = 0; c < p.C; ++c) {                 // lam_prior = eye * l; eta = lam_prior @ mu  (gbp_ba.py:32-34)
-        for (int k = 0; k < 6; ++k) {
-            cp[(size_t)c * 27 + k] = cam_lambda[c] * cb[(size_t)c * CAMREC + CAM_MU + k];
-            cp[(size_t)c * 27 + 6 + Sym<6>::at(k, k)] = cam_lambda[c];
-        }
-    }
-    for (int l = 0; l < p.L; ++l) {
-        for (int k = 0; k < 3; ++k) {
-            lp[(size_t)l * 9 + k] = lmk_lambda[l] * lr[(size_t)l * LREC + LR_MU + k];
-            lp[(size_t)l * 9 + 3 + Sym<3>::at(k, k)] = lmk_lambda[l];
-        }
-    }
-    CHK(upload(h, p.cprior, cp));
-    return upload_lmk_priors(h, lp);
+    if (p.C) HIPCHK(hipMemcpyAsync(h->d_varmax, cam_lambda, sizeof(double) * (size_t)p.C, hipMemcpyHostToDevice, h->stream));
+    if (p.L) HIPCHK(hipMemcpyAsync(h->d_varmax + p.C, lmk_lambda, sizeof(double) * (size_t)p.L, hipMemcpyHostToDevice, h->stream));
+    if (p.C + p.L) hipLaunchKernelGGL(k_prior_scalars, dim3(grid_for((size_t)p.C + p.L)), dim3(BLOCK), 0, h->stream, p, h->d_varmax, h->d_varmax + p.C, 1.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));               // the arrays are the caller's
+    return GBP_OK;
 }
 
 int gbp_ba_generate_priors(gbp_ba_t *h, double weaker_factor)
@@ -662,12 +649,12 @@ int gbp_ba_generate_priors(gbp_ba_t *h, double weaker_factor)
     ENTER(h);
     h->resid_ok = false;
     if (!(weaker_factor != 0.0)) return fail(GBP_EINVAL, "weaker_factor must be non-zero");
-    std::vector<double> cm((size_t)h->p.C), lm((size_t)h->p.L);
-    CHK(gbp_ba_factor_lambda_max(h, cm.data(), lm.data()));
-    const double w2 = weaker_factor * weaker_factor;
-    for (double &v : cm) v = v / w2;
-    for (double &v : lm) v = v / w2;
-    return gbp_ba_set_prior_scalars(h, cm.data(), lm.data());
+    const Params &p = h->p;
+    CHK(variable_lambda_max(h));                           // nothing F-sized leaves the device
+    if (p.C + p.L) hipLaunchKernelGGL(k_prior_scalars, dim3(grid_for((size_t)p.C + p.L)), dim3(BLOCK), 0, h->stream, p, h->d_varmax,
+                                      h->d_varmax + p.C, weaker_factor * weaker_factor);
+    HIPCHK(hipGetLastError());
+    return GBP_OK;
 }
 
 int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam, const double *lmk_eta, const double *lmk_lam)
@@ -690,7 +677,11 @@ int gbp_ba_set_priors(gbp_ba_t *h, const double *cam_eta, const double *cam_lam,
                 lp[(size_t)l * 9 + 3 + Sym<3>::at(i, j)] = 0.5 * (lmk_lam[(size_t)l * 9 + i * 3 + j] + lmk_lam[(size_t)l * 9 + j * 3 + i]);
     }
     CHK(upload(h, p.cprior, cp));
-    return upload_lmk_priors(h, lp);
+    CHK(ensure_tmp(h, sizeof(double) * lp.size()));
+    CHK(upload(h, h->d_tmp, lp));
+    if (p.L) hipLaunchKernelGGL(k_scatter_lmk_priors, dim3(grid_for((size_t)p.L * 9)), dim3(BLOCK), 0, h->stream, p, h->d_tmp);
+    HIPCHK(hipGetLastError());
+    return GBP_OK;
 }
 
 int gbp_ba_weaken_priors(gbp_ba_t *h, double factor)
@@ -1002,8 +993,9 @@ int gbp_ba_get_factors(gbp_ba_t *h, int32_t f0, int32_t n, double *eta, double *
     ENTER(h);
     CHK(check_range(h, f0, n));
     const Params &p = h->p;
-    if (cam) for (int q = 0; q < n; ++q) cam[q] = h->ref_cam[f0 + q];
-    if (lmk) for (int q = 0; q < n; ++q) lmk[q] = h->ref_lmk[f0 + q];
+    if (cam && n) HIPCHK(hipMemcpyAsync(cam, h->d_ref_cam + f0, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (lmk && n) HIPCHK(hipMemcpyAsync(lmk, h->d_ref_lmk + f0, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if ((cam || lmk) && n) HIPCHK(hipStreamSynchronize(h->stream));
     if ((linpoint || meas) && n) {                                  // gathered on the device: only the requested range moves
         CHK(ensure_tmp(h, sizeof(double) * 11 * (size_t)n));
         double *d_x0 = h->d_tmp, *d_z = h->d_tmp + 9 * (size_t)n;
@@ -1212,24 +1204,25 @@ struct StateHeader {
     char magic[8];                 // "GBPSTATE"
     uint32_t version, has_beliefs;
     int32_t F, T, L, C;
-    uint64_t graph_hash;           // FNV-1a over the factor -> (slot, camera, landmark) maps
+    uint64_t graph_hash;           // digest of the factor -> (slot, camera, landmark) maps (k_graph_hash)
     uint64_t payload_bytes;
 };
 
-uint64_t fnv1a(uint64_t hsh, const void *data, size_t n)
+int graph_hash(gbp_ba *h, uint64_t *out)
 {
-    const unsigned char *b = static_cast<const unsigned char *>(data);
-    for (size_t i = 0; i < n; ++i) { hsh ^= b[i]; hsh *= 1099511628211ull; }
-    return hsh;
-}
-
-uint64_t graph_hash(const gbp_ba *h)
-{
-    uint64_t v = 1469598103934665603ull;
-    v = fnv1a(v, h->ref2slot.data(), h->ref2slot.size() * sizeof(int32_t));
-    v = fnv1a(v, h->ref_cam.data(), h->ref_cam.size() * sizeof(int32_t));
-    v = fnv1a(v, h->ref_lmk.data(), h->ref_lmk.size() * sizeof(int32_t));
-    return v;
+    if (!h->hash_ok) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(h->d_count);      // 8 bytes
+        HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), h->stream));
+        if (h->p.F) hipLaunchKernelGGL(k_graph_hash, dim3(grid_for((size_t)h->p.F)), dim3(BLOCK), 0, h->stream, h->p.cadj, h->d_ref_cam,
+                                       h->d_ref_lmk, h->p.F, d);
+        HIPCHK(hipGetLastError());
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->hash = v; h->hash_ok = true;
+    }
+    *out = h->hash;
+    return GBP_OK;
 }
 
 struct StatePart { void *dev; size_t bytes; };
@@ -1263,9 +1256,9 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
-    hd.version = 1; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.version = 2; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
-    hd.graph_hash = graph_hash(h);
+    CHK(graph_hash(h, &hd.graph_hash));
     hd.payload_bytes = need - sizeof(StateHeader);
     char *out = static_cast<char *>(buf);
     std::memcpy(out, &hd, sizeof hd);
@@ -1287,8 +1280,10 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
-    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 1) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
-    if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != graph_hash(h))
+    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 2) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
+    uint64_t mine = 0;
+    CHK(graph_hash(h, &mine));
+    if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)
         return fail(GBP_EINVAL, "state blob belongs to a different graph (F/L/C or factor order differ)");
     if (bytes < need || hd.payload_bytes != need - sizeof(StateHeader)) return fail(GBP_EINVAL, "state blob truncated");
     const char *in = static_cast<const char *>(buf) + sizeof hd;
@@ -1367,6 +1362,22 @@ int gbp_ba_eval_fn(const double *K4, int32_t n, const double *x9, double *h2, do
     if (e == hipSuccess && hproj2) e = hipMemcpy(hproj2, d_hp, sizeof(double) * 2 * N, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(GBP_EHIP, "gbp_ba_eval_fn: %s", hipGetErrorString(e));
+    return GBP_OK;
+}
+
+int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots)
+{
+    ENTER(h);
+    if (!bad_slots) return fail(GBP_EINVAL, "null argument");
+    *bad_slots = 0;
+    if (!h->p.T) return GBP_OK;
+    HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_check_layout, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, h->d_ref_cam, h->d_ref_lmk, h->d_count);
+    HIPCHK(hipGetLastError());
+    int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *bad_slots = v;
     return GBP_OK;
 }
 

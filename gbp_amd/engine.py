@@ -28,8 +28,14 @@ def eval_fn(K4, x9, device=0):
 class BAEngine:
     def __init__(self, K, cam_means, lmk_means, meas, cam_idx, lmk_idx, *, gauss_noise_std=2.0, loss=None,
                  Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8, eta_damping=0.4,
-                 device=0, fused=True):
+                 device=0, fused=True, device_pointers=None):
+        """device_pointers = (C, L, F): the five arrays are then integer DEVICE addresses on `device` (float64 cam_means[C,6],
+        lmk_means[L,3], meas[F,2]; int32 cam_idx[F], lmk_idx[F]) and nothing is uploaded (GBP_FLAG_DEVICE_INPUT)."""
         self._lib = _capi.load()
+        if device_pointers is not None:
+            return self._init_from_device(K, cam_means, lmk_means, meas, cam_idx, lmk_idx, device_pointers,
+                                          gauss_noise_std, loss, Nstds, beta, num_undamped_iters, min_linear_iters,
+                                          eta_damping, device, fused)
         K = np.asarray(K, dtype=np.float64)
         if K.shape == (3, 3):
             K = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
@@ -55,6 +61,30 @@ class BAEngine:
         d.loss = _capi.LOSS[loss]
         d.num_undamped_iters, d.min_linear_iters = int(num_undamped_iters), int(min_linear_iters)
         d.flags = 0 if fused else _capi.FLAG_NO_FUSED
+        d.nstds, d.beta, d.eta_damping = float(Nstds), float(beta), float(eta_damping)
+        self._h = ct.c_void_p()
+        check(self._lib.gbp_ba_create(ct.byref(self._h), ct.byref(d)))
+
+    def _init_from_device(self, K, cam_means, lmk_means, meas, cam_idx, lmk_idx, sizes, gauss_noise_std, loss, Nstds, beta,
+                          num_undamped_iters, min_linear_iters, eta_damping, device, fused):
+        K = f64(np.asarray(K, dtype=np.float64).reshape(-1), (4,))
+        self.C, self.L, self.F = (int(v) for v in sizes)
+        if loss not in _capi.LOSS:
+            raise ValueError(f"unknown loss {loss!r} (None, 'huber', 'constant')")
+        self.K = K.copy()
+        self.eta_damping = float(eta_damping)
+        d = _capi.Desc()
+        d.n_cams, d.n_lmks, d.n_factors, d.device = self.C, self.L, self.F, int(device)
+        d.K[:] = list(K)
+        d.cam_means = ct.cast(ct.c_void_p(int(cam_means)), _capi._dp)
+        d.lmk_means = ct.cast(ct.c_void_p(int(lmk_means)), _capi._dp)
+        d.meas = ct.cast(ct.c_void_p(int(meas)), _capi._dp)
+        d.cam_idx = ct.cast(ct.c_void_p(int(cam_idx)), _capi._ip)
+        d.lmk_idx = ct.cast(ct.c_void_p(int(lmk_idx)), _capi._ip)
+        d.gauss_noise_std = float(gauss_noise_std)
+        d.loss = _capi.LOSS[loss]
+        d.num_undamped_iters, d.min_linear_iters = int(num_undamped_iters), int(min_linear_iters)
+        d.flags = (0 if fused else _capi.FLAG_NO_FUSED) | _capi.FLAG_DEVICE_INPUT
         d.nstds, d.beta, d.eta_damping = float(Nstds), float(beta), float(eta_damping)
         self._h = ct.c_void_p()
         check(self._lib.gbp_ba_create(ct.byref(self._h), ct.byref(d)))
@@ -299,6 +329,12 @@ class BAEngine:
         out = np.empty(n.value)
         check(self._lib.gbp_ba_get_kernel_times(self._h, dptr(out), n.value, ct.byref(n)))
         return out
+
+    def check_layout(self):
+        """Debug kernel: number of slots that do not decode to the reference factor they hold (0 for a sound layout)."""
+        v = ct.c_int32()
+        check(self._lib.gbp_ba_check_layout(self._h, ct.byref(v)))
+        return v.value
 
     def info(self):
         a, b, c = ct.c_int32(), ct.c_int32(), ct.c_int32()

@@ -66,6 +66,8 @@ typedef struct gbp_ba_desc {
 } gbp_ba_desc_t;
 
 #define GBP_FLAG_NO_FUSED 1       /* force the general 3-kernel sweep (testing / ablation) */
+#define GBP_FLAG_DEVICE_INPUT 2   /* cam_means / lmk_means / meas / cam_idx / lmk_idx are DEVICE pointers (on desc.device): nothing is
+                                     uploaded; the graph is ordered, tiled and linearised where the observations already are */
 
 int gbp_abi_version(void);
 const char *gbp_last_error(void);
@@ -179,6 +181,7 @@ int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
 int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);
 int gbp_ba_get_kernel_times(gbp_ba_t *h, double *ms, int32_t cap, int32_t *n_launches);   /* each bracketed launch, in order; call BEFORE get_kernel_timing (which resets) */
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);
+int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots);   /* debug: slots whose (camera, landmark) do not match the reference factor they hold (0 = sound) */
 int gbp_ba_fused_max_cams(void);    /* most cameras the fused sweep takes (camera table + wave scratch in 160 KB of LDS); above it the general sweep runs */
 
 #ifdef __cplusplus
