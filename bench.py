@@ -18,7 +18,7 @@ steady sweeps (fewer than 1 factor in 1000 relinearises: the case SURVEY 8d's by
 sweeps are reported separately.
 
 Roofline bookkeeping.  `roofline.achieved` = the bytes the engine's data layout MUST move per launch of the dominant
-kernel (F (26 read + 15 written doubles + 12 B of indices / state) + L (24 + 12 doubles) + one
+kernel (F (21 read + 10 written doubles + 12 B of indices / state) + L (24 + 12 doubles) + one
 camera table per workgroup) / the mean steady launch time; `frac` = achieved / 8 TB/s, never above 1.  `traffic` = HBM
 bytes per launch measured by the PMC passes committed under profiles/.  The survey's 1072 B/factor model of a dense
 two-pass implementation is kept only as `survey_equivalent_*`: this engine does that work in fewer bytes.
@@ -49,10 +49,10 @@ def survey_bytes(F, L, C):
 
 def layout_bytes(F, L, C, n_blocks, fused):
     """Bytes one launch of the dominant kernel must move in THIS engine's layout."""
-    if fused:       # k_sweep_wat: x0 9 z 2 | msgs 15 in, 15 out | meta 4 B, state 4 B in + 4 B out; landmark record 24 in, belief+mean 12 out; tables out
-        return F * ((26 + 15) * 8 + 12) + L * (24 + 12) * 8 + n_blocks * C * 27 * 8
+    if fused:       # k_sweep_wat: x0 9 z 2 | msgs 10 in, 10 out | meta 4 B, state 4 B in + 4 B out; landmark record 24 in, belief+mean 12 out; tables out
+        return F * ((21 + 10) * 8 + 12) + L * (24 + 12) * 8 + n_blocks * C * 27 * 8
     # k_factor_tile: the same per-factor / per-landmark streams + the dense camera message staged camera-major (27 doubles + cpos)
-    return F * ((26 + 15) * 8 + 12 + 27 * 8 + 4) + L * (24 + 12) * 8
+    return F * ((21 + 10) * 8 + 12 + 27 * 8 + 4) + L * (24 + 12) * 8
 
 
 def host_cores():
@@ -255,7 +255,7 @@ def main():
         traffic, traffic_src = measured_traffic() if (world == 1 and fused and F == 1_000_000 and not dry) else (None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": k_name, "bytes_per_launch": lay,
-                "bytes_model": "engine layout, DESIGN.md section 4: F*(41 doubles + 12 B) + L*36 doubles + camera tables",
+                "bytes_model": "engine layout, DESIGN.md section 4: F*(31 doubles + 12 B) + L*36 doubles + camera tables",
                 "kernel_avg_ms": k_steady, "kernel_median_ms": float(np.median(k_times[steady])) if k_times.size else 0.0,
                 "kernel_min_ms": float(k_times[steady].min()) if k_times.size else 0.0,
                 "kernel_launches_timed": int(steady.sum()), "kernel_timing": "HIP events around every launch, separate replay of the batch",

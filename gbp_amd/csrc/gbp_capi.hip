@@ -189,10 +189,18 @@ static int launch_factor_stage(gbp_ba *h, int robustify, int local_relin)
     if (!p.T) return GBP_OK;
     const int nb = (p.T + BLOCK / 64 - 1) / (BLOCK / 64);
     CHK(time_begin(h));
-    switch (p.loss) {
-    case GBP_LOSS_NONE: hipLaunchKernelGGL(k_factor_tile<0>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
-    case GBP_LOSS_HUBER: hipLaunchKernelGGL(k_factor_tile<1>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
-    default: hipLaunchKernelGGL(k_factor_tile<2>, dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+    if (p.xtra) {
+        switch (p.loss) {
+        case GBP_LOSS_NONE: hipLaunchKernelGGL((k_factor_tile<0, true>), dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+        case GBP_LOSS_HUBER: hipLaunchKernelGGL((k_factor_tile<1, true>), dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+        default: hipLaunchKernelGGL((k_factor_tile<2, true>), dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+        }
+    } else {
+        switch (p.loss) {
+        case GBP_LOSS_NONE: hipLaunchKernelGGL((k_factor_tile<0, false>), dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+        case GBP_LOSS_HUBER: hipLaunchKernelGGL((k_factor_tile<1, false>), dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+        default: hipLaunchKernelGGL((k_factor_tile<2, false>), dim3(nb), dim3(BLOCK), 0, h->stream, p); break;
+        }
     }
     CHK(time_end(h));
     HIPCHK(hipGetLastError());
@@ -486,6 +494,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     // 5. per-slot data
     unsigned *d_meta = nullptr; int4 *d_tiles = nullptr; int *d_lrow0 = nullptr, *d_lrow1 = nullptr;
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
+    if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
     CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1), false));
     CHK(scratch_alloc(scratch, &d_lrow0, (size_t)L)); CHK(scratch_alloc(scratch, &d_lrow1, (size_t)L));
@@ -516,7 +525,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         CHK(gbp_ba_check_layout(h, &bad));
         if (bad) return fail(GBP_ESTATE, "internal layout error: %d slots do not decode to their reference factor", bad);
     }
-    if (!(h->flags & GBP_FLAG_NO_FUSED)) {
+    if (!(h->flags & GBP_FLAG_NO_FUSED) && !p.xtra) {
         HIPCHK(hipStreamSynchronize(h->stream));            // tiles[].w (max rank) is written by k_build_tiles
         int rc = fused_plan(h->fused, p, h->big_lmks, h->stream, n_cus);
         if (rc < 0) return fail(GBP_EHIP, "building the fused sweep plan failed (%d)", rc);
@@ -1233,7 +1242,7 @@ std::vector<StatePart> state_parts(gbp_ba *h)
     const size_t S = (size_t)p.T * WTILE;
     return {{p.lin, S * LIN_ROWS * sizeof(double)}, {p.msg, S * MSG_ROWS * sizeof(double)}, {p.state, S * sizeof(int)},
             {p.lrec, (size_t)p.L * LREC * sizeof(double)}, {p.cbel, (size_t)p.C * CAMREC * sizeof(double)},
-            {p.cprior, (size_t)p.C * 27 * sizeof(double)}};
+            {p.cprior, (size_t)p.C * 27 * sizeof(double)}, {p.xtra, p.xtra ? S * XTRA_ROW * sizeof(double) : 0}};
 }
 }  // namespace
 }  // extern "C++"
@@ -1256,7 +1265,7 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
-    hd.version = 2; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.version = 3; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
     CHK(graph_hash(h, &hd.graph_hash));
     hd.payload_bytes = need - sizeof(StateHeader);
@@ -1280,7 +1289,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
-    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 2) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
+    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 3) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)

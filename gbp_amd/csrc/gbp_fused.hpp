@@ -22,9 +22,9 @@
 //     (workgroup, tile, rank) -- independent of which wave ran which tile and of timing.  Within a rank round
 //     every lane targets a different camera, so the LDS ds_add_f64 is a plain read-modify-write.
 //
-// HBM traffic per sweep: F*(26 read + 15 written doubles + 12 B of indices) + L*(24 read + 12 written doubles)
-// + the workgroup tables (256 * C * 27 doubles written and read once) -- well under half of the "algorithmic"
-// 1072 B per factor of SURVEY.md 8d, which assumed dense message precisions and a second pass over the messages.
+// HBM traffic per sweep: F*(21 read + 10 written doubles + 12 B of indices) + L*(24 read + 12 written doubles)
+// + the workgroup tables (256 * C * 27 doubles written and read once) -- under a third of the "algorithmic"
+// 1072 B per factor of SURVEY.md 8d, which assumed dense messages and a second pass over them.
 //
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        double x0[9], z[2], avar = p.sigma2, eC[6], eL[3], WC[3], VL[3], muC[6], ceC[6], clC[21];
+        double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], etaC[6], clC[21];
         const unsigned meta = p.meta[slot];
         int st = p.state[slot];
 #pragma unroll
@@ -109,9 +109,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
         if (LOSS != 0) avar = p.lin[lin_at(slot, ROW_AVAR)];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+        for (int k = 0; k < 2; ++k) { qC[k] = p.msg[msg_at(slot, ROW_QC + k)]; qL[k] = p.msg[msg_at(slot, ROW_QL + k)]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
@@ -141,9 +139,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 
         // the camera record of this tile's factors: a gather that needs `meta` (L2 hits)
         const int cam = active ? (int)(meta >> META_LMK_BITS) : 0;
-        load_cam_record(p.cbel + (size_t)cam * CAMREC, ceC, clC, muC);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ceC[k] -= eC[k];
+        load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, clC, muC);
         asm volatile("" ::: "memory");
 
         if (!valid) break;
@@ -170,13 +166,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         }
         wave_lds_sync();
 
-        double MCn[21];
+        double MCn[21], eC[6];
         if (active) {
-            double MLn[6];
+            double MLn[6], eL[3];
             const double *lbel = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC + LR_BEL;   // still intact: messages go in below
-            const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, ceC, clC,
-                                                 [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
-                                                 clL, eC, eL, WC, VL, MCn, MLn);
+            const bool relin = factor_core<LOSS, false>(p, x0, z, st, avar, muC, muL, etaC, clC,
+                                                        [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
+                                                        clL, qC, qL, WC, VL, eC, eL, MCn, MLn);
             n_relin += relin_in_wave(relin);
             int sslot = slot;
             asm volatile("" : "+v"(sslot));             // store addresses are recomputed here, not kept alive (and spilled) through the maths
@@ -185,9 +181,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
                 for (int k = 0; k < 9; ++k) p.lin[lin_at(sslot, ROW_X0 + k)] = x0[k];
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) p.msg[msg_at(sslot, ROW_EC + k)] = eC[k];
+            for (int k = 0; k < 2; ++k) { p.msg[msg_at(sslot, ROW_QC + k)] = qC[k]; p.msg[msg_at(sslot, ROW_QL + k)] = qL[k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { p.msg[msg_at(sslot, ROW_EL + k)] = eL[k]; wl[lane * 9 + k] = eL[k]; }
+            for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) p.msg[msg_at(sslot, ROW_WC + k)] = WC[k];
 #pragma unroll

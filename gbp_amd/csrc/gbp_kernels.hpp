@@ -12,13 +12,13 @@
 //     lin[tile][12][64]   rows 0-8 x0 = linearisation point (t, w, y)      Factor.linpoint      gbp.py:231
 //                         rows 9-10 z  = measurement                        Factor.measurement   gbp.py:233
 //                         row  11  adaptive noise variance (loss != none)   gbp.py:242
-//     msg[tile][16][64]   rows 0-5 eta of the message to the camera, rows 6-8 eta of the message to the landmark,
-//                         rows 9-11 / 12-14 the 2x2 cores W / V of the two message precisions (Lambda = J^T Q J with
-//                         J at x0: gbp_math.hpp rank2_update), row 15 pad            Factor.messages  gbp.py:222
+//     msg[tile][10][64]   rows 0-1 / 2-3 the coefficients q_C / q_L of the two message etas (eta = J^T q with J at x0),
+//                         rows 4-6 / 7-9 the 2x2 cores W / V of the two message precisions (Lambda = J^T Q J:
+//                         gbp_math.hpp rank2_update)                                  Factor.messages  gbp.py:222
 //     state[slot] int32 = iters_since_relin << 12 | rank << 2 | robust << 1 | damped     gbp.py:245-249
 //     meta[slot] uint32 = camera index << 8 | landmark's position inside its tile
 // so a wave's access is one contiguous 1 KB line per row pair and a tile's whole working set is one
-// 8 KB + 6 KB block (the reference's dense messages would be 27 KB: Lambda 6x6 + 3x3 per factor).  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
+// 5 KB + 6 KB block (the reference's dense messages would be 27 KB: eta 6 + 3, Lambda 6x6 + 3x3 per factor).  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
 // stride-F arrays reach 3.9 TB/s at 4 waves/CU, as tile-contiguous blocks 5.4 TB/s.)
 // Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt from x0 and z
 // every sweep (2x9 Jacobian ~ 150 flops versus 720 bytes of traffic).
@@ -39,9 +39,10 @@ namespace gbp {
 
 constexpr int WTILE = 64;         // slots per tile = lanes per wavefront
 constexpr int TILE_LMKS = 24;     // most landmarks a tile owns
-constexpr int LIN_ROWS = 12, MSG_ROWS = 16;
+constexpr int LIN_ROWS = 12, MSG_ROWS = 10;
 constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_AVAR = 11;
-constexpr int ROW_EC = 0, ROW_EL = 6, ROW_WC = 9, ROW_VL = 12;
+constexpr int ROW_QC = 0, ROW_QL = 2, ROW_WC = 4, ROW_VL = 7;
+constexpr int XTRA_ROW = 9;       // doubles per slot of the dense remainder (num_undamped_iters = 0 only): camera 6 | landmark 3
 constexpr int LREC = 24;          // doubles per landmark record
 constexpr int LR_BEL = 0, LR_MU = 9, LR_PRIOR = 12, LR_ROWS = 21;
 constexpr int CAMREC = 34;        // doubles per camera record
@@ -66,6 +67,8 @@ struct Params {
     const int *cptr, *cadj;
     double *cstage;               // general sweep: [F][27] camera messages in camera-major (reference) order, or NULL
     const int *cpos;              // slot -> row of cstage
+    double *xtra;                 // [slot][9] out-of-span remainder of the message etas, or NULL (gbp_math.hpp header: only when
+                                  // num_undamped_iters = 0 lets a factor be damped in the sweep it relinearises in)
     int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
 };
 
@@ -148,25 +151,48 @@ GBP_DEV void factor_linearise(const Params &p, const double (&x0)[9], const doub
 
 // One factor's sweep in registers (gbp.py:82-84, 64-80, 46-54, 334-373).
 //   in : x0, z, state, adaptive variance, means of the two beliefs,
-//        ceC = eta_C - e_C(old), clC = Lambda_C,  lmk_belief_eta(out[3]) yields eta_L when it is needed, clL = Lambda_L
+//        etaC = eta_C, clC = Lambda_C (camera belief),  lmk_belief_eta(out[3]) yields eta_L when it is needed, clL = Lambda_L
 //        (cl* are consumed),
-//        old message etas eC / eL and old cores WC / VL
-//   out: new eC / eL / WC / VL (both messages from the OLD ones, gbp.py:371-373), dense new Lambda MCn / MLn for the
-//        belief sums, x0 / state / avar updated; returns true when the factor relinearised (x0 changed).
-template <int LOSS, typename LmkEta>
+//        old message coefficients qC / qL and old cores WC / VL
+//   out: new qC / qL / WC / VL (both messages from the OLD ones, gbp.py:371-373), dense new etas eCn / eLn and Lambdas
+//        MCn / MLn for the belief sums, x0 / state / avar updated; returns true when the factor relinearised (x0 changed).
+//   XTRA: xt = this slot's dense remainder (read and updated), see Params::xtra.
+template <int LOSS, bool XTRA, typename LmkEta>
 GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
                          const double (&muC)[6], const double (&muL)[3],
-                         const double (&ceC)[6], double (&clC)[21], LmkEta &&lmk_belief_eta, double (&clL)[6],
-                         double (&eC)[6], double (&eL)[3], double (&WC)[3], double (&VL)[3],
-                         double (&MCn)[21], double (&MLn)[6])
+                         const double (&etaC)[6], double (&clC)[21], LmkEta &&lmk_belief_eta, double (&clL)[6],
+                         double (&qC)[2], double (&qL)[2], double (&WC)[3], double (&VL)[3],
+                         double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr)
 {
     double d;
     const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
     Lin L;
     factor_linearise(p, x0, z, avar, d, L);
-    // cavities: belief minus this factor's OLD message, whose precision lives in the span of the OLD Jacobian
+    // cavities: belief minus this factor's OLD message, which lives in the span of the OLD Jacobian
+    double ceC[6], eLold[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ceC[i] = etaC[i] - (L.Jc[0][i] * qC[0] + L.Jc[1][i] * qC[1]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eLold[i] = L.Jl[0][i] * qL[0] + L.Jl[1][i] * qL[1];
     rank2_update<6>(clC, L.Jc[0], L.Jc[1], WC, -1.0);
     rank2_update<3>(clL, L.Jl[0], L.Jl[1], VL, -1.0);
+    double xn[XTRA ? XTRA_ROW : 1];
+    if (XTRA) {
+        // e_old = J_old^T q_old + x_old.  Damped in the very sweep it relinearises: d e_old leaves the span of the new
+        // Jacobian and is carried densely; otherwise only the old remainder decays.
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double eo = etaC[i] - ceC[i] + xt[i];            // the old dense message to the camera
+            ceC[i] -= xt[i];
+            xn[i] = relin ? d * eo : d * xt[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            eLold[i] += xt[6 + i];
+            xn[6 + i] = relin ? d * eLold[i] : d * xt[6 + i];
+        }
+        if (relin) { qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0; }
+    }
     if (relin) {                                           // gbp.py:75-78: linearise again at the belief means
 #pragma unroll
         for (int i = 0; i < 6; ++i) x0[i] = muC[i];
@@ -174,15 +200,20 @@ GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2],
         for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
         factor_linearise(p, x0, z, avar, d, L);
     }
-    double eLn[3];
-    message_to_landmark_cavity(L, ceC, clC, eL, eLn, MLn, VL);
+    double qLn[2];
+    message_to_landmark_cavity(L, ceC, clC, qL, qLn, eLn, MLn, VL);
     double ceL[3];                                         // fetched only now: three doubles less through the 6x6 elimination
     lmk_belief_eta(ceL);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ceL[i] -= eL[i];
-    message_to_camera_cavity(L, ceL, clL, eC, MCn, WC);
+    for (int i = 0; i < 3; ++i) ceL[i] -= eLold[i];
+    message_to_camera_cavity(L, ceL, clL, qC, eCn, MCn, WC);
+    qL[0] = qLn[0]; qL[1] = qLn[1];
+    if (XTRA) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) eL[i] = eLn[i];
+        for (int i = 0; i < 6; ++i) { eCn[i] += xn[i]; xt[i] = xn[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { eLn[i] += xn[6 + i]; xt[6 + i] = xn[6 + i]; }
+    }
     return relin;
 }
 
@@ -197,8 +228,8 @@ GBP_DEV void relin_add(const Params &p, int n)                                  
     if (p.relin_slot && n) atomicAdd(p.relin_slot + (blockIdx.x & (RELIN_LANES - 1)), n);
 }
 
-// The dense messages of a slot (for the belief sums of the general path and the parity views): the precisions are
-// rebuilt from their cores at the stored linearisation point.
+// The dense messages of a slot (for the belief sums of the general path and the parity views): etas and precisions are
+// rebuilt from their coefficients / cores at the stored linearisation point.
 GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6]);
 
 GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], double (&lam)[21], double (&mu)[6])
@@ -228,18 +259,20 @@ GBP_DEV bool slot_info(const Params &p, int slot, int &cam, int &lmk)
 
 GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6])
 {
-    double x0[9], Jc[2][6], Jl[2][3], h[2], WC[3], VL[3];
+    double x0[9], Jc[2][6], Jl[2][3], h[2], qC[2], qL[2], WC[3], VL[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
     linearise(x0, p.K, Jc, Jl, h);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+    for (int k = 0; k < 2; ++k) { qC[k] = p.msg[msg_at(slot, ROW_QC + k)]; qL[k] = p.msg[msg_at(slot, ROW_QL + k)]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
     for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) eC[k] = Jc[0][k] * qC[0] + Jc[1][k] * qC[1] + (p.xtra ? p.xtra[(size_t)slot * XTRA_ROW + k] : 0.0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) eL[k] = Jl[0][k] * qL[0] + Jl[1][k] * qL[1] + (p.xtra ? p.xtra[(size_t)slot * XTRA_ROW + 6 + k] : 0.0);
 #pragma unroll
     for (int k = 0; k < 21; ++k) MC[k] = 0.0;
 #pragma unroll
@@ -257,7 +290,7 @@ GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (
 //   * the dense message to the camera (eta 6 | Lambda 21) is written to cstage[cpos[slot]], i.e. in the camera's own
 //     adj_factors order, so k_cam_partial_staged reads one contiguous run per camera instead of gathering 16-byte
 //     pieces and rebuilding Jacobians (k_cam_partial fetches 562 MB per sweep at 1M factors; this is 216 + 216 MB).
-template <int LOSS>
+template <int LOSS, bool XTRA>
 __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 {
     __shared__ double wls[BLOCK / 64][WTILE * 27];          // per wave: [64][9] landmark messages, then [64][27] camera messages
@@ -275,14 +308,12 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     if (active) {
         const unsigned meta = p.meta[slot];
         const int cam = (int)(meta >> META_LMK_BITS), lmk = l0 + (int)(meta & ((1u << META_LMK_BITS) - 1u));
-        double x0[9], z[2], eC[6], eL[3], WC[3], VL[3];
+        double x0[9], z[2], qC[2], qL[2], WC[3], VL[3];
 #pragma unroll
         for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
         z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eC[k] = p.msg[msg_at(slot, ROW_EC + k)];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) eL[k] = p.msg[msg_at(slot, ROW_EL + k)];
+        for (int k = 0; k < 2; ++k) { qC[k] = p.msg[msg_at(slot, ROW_QC + k)]; qL[k] = p.msg[msg_at(slot, ROW_QL + k)]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
@@ -296,13 +327,12 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) etaC[k] -= eC[k];
 
-        double MCn[21], MLn[6];
-        const bool relin = factor_core<LOSS>(p, x0, z, st, avar, muC, muL, etaC, lamC,
-                                             [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
-                                             lamL, eC, eL, WC, VL, MCn, MLn);
+        double eCn[6], eLn[3], MCn[21], MLn[6];
+        const bool relin = factor_core<LOSS, XTRA>(p, x0, z, st, avar, muC, muL, etaC, lamC,
+                                                   [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
+                                                   lamL, qC, qL, WC, VL, eCn, eLn, MCn, MLn,
+                                                   XTRA ? p.xtra + (size_t)slot * XTRA_ROW : nullptr);
         {
             const unsigned long long rb = __ballot(relin);
             if (rb != 0ull && lane == __ffsll((long long)rb) - 1) relin_add(p, __popcll(rb));
@@ -312,20 +342,20 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
             for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p.msg[msg_at(slot, ROW_EC + k)] = eC[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { p.msg[msg_at(slot, ROW_EL + k)] = eL[k]; wl[lane * 9 + k] = eL[k]; }
+        for (int k = 0; k < 2; ++k) { p.msg[msg_at(slot, ROW_QC + k)] = qC[k]; p.msg[msg_at(slot, ROW_QL + k)] = qL[k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eLn[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
         p.state[slot] = st;
         if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
         wp[lane] = p.cpos[slot];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eCout[k] = eC[k];
+        for (int k = 0; k < 6; ++k) eCout[k] = eCn[k];
 #pragma unroll
         for (int k = 0; k < 21; ++k) MCout[k] = MCn[k];
     }

@@ -23,7 +23,13 @@
 //     inverse of the reference is replaced by an unpivoted LDL^T on packed upper storage, and only
 //     the forward substitution is needed: X^T S^-1 Y = (L^-1 X)^T D^-1 (L^-1 Y).
 //   * symmetric matrices are stored packed (upper triangle, row-major): 6x6 -> 21, 3x3 -> 6;
-//   * message precisions are stored as their 2x2 cores (M = J^T Q J): 3 doubles instead of 21 / 6 (rank2_update).
+//   * message precisions are stored as their 2x2 cores (M = J^T Q J): 3 doubles instead of 21 / 6 (rank2_update);
+//   * message etas are stored as their 2-vectors of coefficients (e = J^T q): 2 doubles instead of 6 / 3.  The new eta is
+//     s J^T (rho - ...) -- in the span of the Jacobian -- and damping (gbp.py:368) mixes it with the old one, which was made
+//     with the same Jacobian unless the factor relinearised in this very sweep; then the damping is 0 (gbp.py:50-54: damping
+//     returns num_undamped_iters sweeps after a relinearisation), so q' = (1-d) r + d q holds in both cases.  The one
+//     configuration where it does not (num_undamped_iters = 0: damped in the relinearising sweep itself) carries the
+//     out-of-span remainder in a dense side array (Params::xtra, general sweep only).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -266,8 +272,10 @@ struct Lin {
 //   M_L' = Jl^T (sI - s^2 Jc T^-1 Jc^T) Jl,  e_L' = (1-d) s Jl^T (rho - Jc T^-1 u) + d e_L
 // The forward substitutions of Jc^T and u ride along with the LDL^T elimination (augmented columns) and the
 // 2x2 quadratic forms are accumulated pivot by pivot, so nothing but the shrinking trailing block stays live.
+//   qLold / qLnew: coefficients of the message eta in the rows of Jl (e_L = Jl^T q_L), eLnew = the dense new eta
 GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], double (&clamC)[21],
-                                        const double (&eLold)[3], double (&eLnew)[3], double (&MLnew)[6], double (&Vcore)[3])
+                                        const double (&qLold)[2], double (&qLnew)[2], double (&eLnew)[3], double (&MLnew)[6],
+                                        double (&Vcore)[3])
 {
     const double s = L.s;
     double y0[6], y1[6], u[6];
@@ -302,9 +310,11 @@ GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], 
         VJ0[j] = V00 * L.Jl[0][j] + V01 * L.Jl[1][j];
         VJ1[j] = V01 * L.Jl[0][j] + V11 * L.Jl[1][j];
     }
+    qLnew[0] = (1.0 - L.d) * r0 + L.d * qLold[0];
+    qLnew[1] = (1.0 - L.d) * r1 + L.d * qLold[1];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        eLnew[i] = (1.0 - L.d) * (L.Jl[0][i] * r0 + L.Jl[1][i] * r1) + L.d * eLold[i];
+        eLnew[i] = L.Jl[0][i] * qLnew[0] + L.Jl[1][i] * qLnew[1];
 #pragma unroll
         for (int j = i; j < 3; ++j) MLnew[Sym<3>::at(i, j)] = L.Jl[0][i] * VJ0[j] + L.Jl[1][i] * VJ1[j];
     }
@@ -313,9 +323,9 @@ GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], 
 // Message to the CAMERA: eliminate the landmark block (3x3).   Factor.compute_messages, v = 0  gbp.py:340-368
 //   cavity of the landmark: cetaL = eta_L - e_L, clamL = Lambda_L - M_L (OLD landmark message)
 //   S = s Jl^T Jl + clamL,  g = s Jl^T rho + cetaL
-//   M_C' = Jc^T (sI - s^2 Jl S^-1 Jl^T) Jc,  e_C' = (1-d) s Jc^T (rho - Jl S^-1 g) + d e_C   (eC in: old, out: new)
+//   M_C' = Jc^T (sI - s^2 Jl S^-1 Jl^T) Jc,  e_C' = (1-d) s Jc^T (rho - Jl S^-1 g) + d e_C = Jc^T q_C'   (qC in: old, out: new)
 GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], double (&clamL)[6],
-                                      double (&eC)[6], double (&MCnew)[21], double (&Wcore)[3])
+                                      double (&qC)[2], double (&eCnew)[6], double (&MCnew)[21], double (&Wcore)[3])
 {
     const double s = L.s;
     double y0[3], y1[3], g[3];
@@ -350,9 +360,11 @@ GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], do
         WJ0[j] = W00 * L.Jc[0][j] + W01 * L.Jc[1][j];
         WJ1[j] = W01 * L.Jc[0][j] + W11 * L.Jc[1][j];
     }
+    qC[0] = (1.0 - L.d) * r0 + L.d * qC[0];
+    qC[1] = (1.0 - L.d) * r1 + L.d * qC[1];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        eC[i] = (1.0 - L.d) * (L.Jc[0][i] * r0 + L.Jc[1][i] * r1) + L.d * eC[i];
+        eCnew[i] = L.Jc[0][i] * qC[0] + L.Jc[1][i] * qC[1];
 #pragma unroll
         for (int j = i; j < 6; ++j) MCnew[Sym<6>::at(i, j)] = L.Jc[0][i] * WJ0[j] + L.Jc[1][i] * WJ1[j];
     }

@@ -167,3 +167,30 @@ def test_out_of_range_ids_are_refused_by_the_device_check():
         li[17] = bad_lmk if bad_lmk else li[17]
         with pytest.raises(_capi.GbpError):
             BAEngine(p.K, p.cam_means, p.lmk_means, p.meas, ci, li)
+
+
+@pytest.mark.parametrize('num_undamped', [0, 1, 2])
+def test_damping_in_the_relinearising_sweep(oracle_mod, num_undamped):
+    """Message etas are stored as 2 coefficients in the rows of the Jacobian (gbp_math.hpp header), exact as long as a factor
+    is never damped in the sweep it relinearises in.  num_undamped_iters = 0 is the one configuration where the reference does
+    that (gbp.py:50-54): the engine then carries the out-of-span remainder densely and runs the general sweep."""
+    from gbp_amd.engine import BAEngine
+    prob = make_synthetic(n_cams=16, n_lmks=400, obs_per_lmk=5, seed=71)
+    kw = dict(num_undamped_iters=num_undamped, min_linear_iters=3, eta_damping=0.4)
+    o = oracle_mod.OracleBA.from_problem(prob, threads=8, **kw)
+    e = BAEngine.from_problem(prob, **kw)
+    assert e.info()['fused'] == (num_undamped > 0)
+    relinearised = 0
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+    for i in range(16):
+        for g in (o, e):
+            g.synchronous_iteration(robustify=True, local_relin=True)
+        relinearised += int((e.relin_state()['iters_since_relin'] == 0).sum())
+        gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs()))
+        assert gap < BELIEF_TOL, (i, gap)
+    assert relinearised > prob.n_factors                    # the case really occurred, more than once per factor
+    for a, b in zip(e.messages(), o.messages()):
+        assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+    assert np.array_equal(o.relin_state()['eta_damping'], e.relin_state()['eta_damping'])
