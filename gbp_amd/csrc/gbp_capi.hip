@@ -1374,6 +1374,22 @@ int gbp_ba_eval_fn(const double *K4, int32_t n, const double *x9, double *h2, do
     return GBP_OK;
 }
 
+// phase profile of the last fused sweep (GBP_PHASE_TIMING builds; rows = workgroups x waves, NPHASE columns of s_memtime ticks)
+int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols)
+{
+    ENTER(h);
+    if (n_rows) *n_rows = 0;
+    if (n_cols) *n_cols = NPHASE;
+    if (!h->fused.enabled || !h->fused.args.phase) return fail(GBP_ESTATE, "not a GBP_PHASE_TIMING build (tools/phase_profile.py)");
+    const int rows = h->fused.n_blocks * WAT_WAVES;
+    if (n_rows) *n_rows = rows;
+    if (out && cap_rows >= rows) {
+        HIPCHK(hipMemcpyAsync(out, h->fused.args.phase, sizeof(uint64_t) * (size_t)rows * NPHASE, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return GBP_OK;
+}
+
 int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots)
 {
     ENTER(h);

@@ -26,6 +26,12 @@
 // + the workgroup tables (256 * C * 27 doubles written and read once) -- under a third of the "algorithmic"
 // 1072 B per factor of SURVEY.md 8d, which assumed dense messages and a second pass over them.
 //
+// Tried and measured on MI355X, not kept (round 2): a software-pipelined loop that requests everything tile k+1 reads (streams,
+// landmark records, camera records) during the back half of tile k.  With no spills and the operands of every tile already on
+// chip when its maths starts ("wait for loads" 1.4 % of the wave-time, tools/phase_profile.py) the sweep was SLOWER, 108 us
+// against 84 us: the time moved into the issue of the stores and the in-order accumulation wait (23 % + 25 %) -- the vector-memory
+// path of the CU (camera gathers: 17 x 64 different lines per tile, streams, stores) and HBM are the limit, not latency.
+//
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
 // (C > 516) the plan stays disabled and the general sweep runs.
@@ -48,12 +54,62 @@ struct FusedArgs {
     double *block_partials;     // [C][n_blocks][27]
     int acc_doubles;            // C*27
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase
+    unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
 };
+
+// Phase profile of the persistent loop (tools/phase_profile.py builds the library with -DGBP_PHASE_TIMING): every wave adds
+// the s_memtime ticks it spends between consecutive marks into its own row.  Off in the product build (no code at all).
+constexpr int NPHASE = 10;
+#ifdef GBP_PHASE_TIMING
+#define GBP_PH_DECL unsigned long long ph_last = __builtin_amdgcn_s_memtime(), ph_acc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define GBP_PH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
+                       ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
+#define GBP_PH_NOWAIT(i) do { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
+#define GBP_PH_FLUSH(ptr, row) do { if ((ptr) && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < NPHASE; ++i_) (ptr)[(size_t)(row) * NPHASE + i_] = ph_acc[i_]; } while (0)
+#else
+#define GBP_PH_DECL
+#define GBP_PH(i)
+#define GBP_PH_NOWAIT(i)
+#define GBP_PH_FLUSH(ptr, row)
+#endif
 
 GBP_DEV void wave_lds_sync()
 {
     // all LDS traffic of this wave issued so far has completed; nothing may be moved across
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// The landmark beliefs of a tile from the wave's LDS scratch: prior + messages in adj_factors order (gbp.py:182-193), then
+// mu = Lambda^-1 eta.  Nine lanes per landmark add one belief entry each (seven landmarks per pass; the order of the additions
+// per entry is the reference's), the sums go back through the prior slots, and one lane per landmark does the 3x3 solve and
+// writes the record.  (One lane per landmark reading 9 doubles per message was the longest phase of the loop: 27 % of the
+// wave-time with 6 of 64 lanes busy, tools/phase_profile.py.)
+GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, double *wp, int lane, int t, int l0, int nl)
+{
+    for (int base = 0; base < nl; base += 7) {
+        const int g = (lane * 57) >> 9;                     // lane / 9 for lane < 64
+        const int li = base + g, k = lane - g * 9;
+        if (g < 7 && li < nl) {
+            double *pr = wp + li * LPRI;
+            const int2 rows = *reinterpret_cast<const int2 *>(pr + 9);
+            double b = pr[k];
+            for (int r = rows.x - t * WTILE; r < rows.y - t * WTILE; ++r) b += wl[r * 9 + k];
+            pr[k] = b;
+        }
+    }
+    wave_lds_sync();
+    if (lane < nl) {
+        const double *pr = wp + lane * LPRI;
+        double b[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = pr[k];
+        double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
+        double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(l0 + lane) * LREC);
+        dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
+        dst[2] = make_double2(b[4], b[5]); dst[3] = make_double2(b[6], b[7]);
+        spd_solve<3>(lam, eta, mu);
+        dst[4] = make_double2(b[8], mu[0]); dst[5] = make_double2(mu[1], mu[2]);
+    }
 }
 
 template <int LOSS, int NWAVES>
@@ -78,8 +134,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     bool pend = false;
     int q_t = 0, q_l0 = 0, q_nl = 0;
     int n_relin = 0;                                      // factors of this wave's tiles that relinearised (wave-uniform)
+    GBP_PH_DECL;
 
     for (;;) {
+        GBP_PH_NOWAIT(9);                                  // loop overhead / after the release of the accumulation ticket
         int ti = 0;
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
@@ -90,6 +148,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
         const int slot = t * WTILE + lane;
+        GBP_PH(0);                                         // ticket + descriptor
 
         // the tile's landmark records (belief | mean | prior | rows) are one contiguous run: the wave fetches it whole
         const int nrec = valid ? max(nl, 1) * LREC : 0;    // chunk tiles stage the over-sized landmark td.x
@@ -115,32 +174,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 #pragma unroll
         for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
         asm volatile("" ::: "memory");
+        GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
         // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
-        if (pend && lane < q_nl && !(a.dbg & 4)) {
-            const double *pr = wp + lane * LPRI;
-            double b[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) b[k] = pr[k];
-            const int2 rows = *reinterpret_cast<const int2 *>(pr + 9);
-            const int row0 = rows.x - q_t * WTILE, row1 = rows.y - q_t * WTILE;
-            for (int r = row0; r < row1; ++r) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) b[k] += wl[r * 9 + k];
-            }
-            double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
-            double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(q_l0 + lane) * LREC);
-            dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
-            dst[2] = make_double2(b[4], b[5]); dst[3] = make_double2(b[6], b[7]);
-            spd_solve<3>(lam, eta, mu);
-            dst[4] = make_double2(b[8], mu[0]); dst[5] = make_double2(mu[1], mu[2]);
-        }
+        if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, wp, lane, q_t, q_l0, q_nl);
         asm volatile("" ::: "memory");
+        GBP_PH_NOWAIT(2);                                  // landmark beliefs of the previous tile (LDS)
 
         // the camera record of this tile's factors: a gather that needs `meta` (L2 hits)
         const int cam = active ? (int)(meta >> META_LMK_BITS) : 0;
+        GBP_PH(3);                                         // the streams (and meta) have arrived
         load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, clC, muC);
         asm volatile("" ::: "memory");
+        GBP_PH(4);                                         // camera gather
 
         if (!valid) break;
 
@@ -165,15 +211,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
             for (int k = 0; k < LPRI / 2; ++k) dst[k] = src[k];
         }
         wave_lds_sync();
+        GBP_PH_NOWAIT(5);                                  // landmark records through LDS
 
         double MCn[21], eC[6];
         if (active) {
             double MLn[6], eL[3];
             const double *lbel = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC + LR_BEL;   // still intact: messages go in below
-            const bool relin = factor_core<LOSS, false>(p, x0, z, st, avar, muC, muL, etaC, clC,
+            Params q = p;
+            pin_scalars(q);
+            const bool relin = factor_core<LOSS, false>(q, x0, z, st, avar, muC, muL, etaC, clC,
                                                         [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
                                                         clL, qC, qL, WC, VL, eC, eL, MCn, MLn);
             n_relin += relin_in_wave(relin);
+            GBP_PH_NOWAIT(6);                              // the maths
             int sslot = slot;
             asm volatile("" : "+v"(sslot));             // store addresses are recomputed here, not kept alive (and spilled) through the maths
             if (relin) {
@@ -194,9 +244,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
             if (LOSS != 0) p.lin[lin_at(sslot, ROW_AVAR)] = avar;
         }
         wave_lds_sync();
+        GBP_PH_NOWAIT(7);                                  // stores issued
         // camera accumulation strictly in tile order
         if (!(a.dbg & 1)) while (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ti) __builtin_amdgcn_s_sleep(2);
         asm volatile("" ::: "memory");
+        GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
         for (int r = 0; r <= maxrank; ++r) {
             if (active && rank == r && !(a.dbg & 2)) {     // one lane per camera in a round: ds_add_f64 is a plain RMW here
@@ -212,6 +264,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         pend = true; q_t = t; q_l0 = l0; q_nl = nl;
     }
     if (lane == 0) relin_add(p, n_relin);
+    GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
     __syncthreads();
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
@@ -333,7 +386,11 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     pl.n_big = (int)big.size();
     if (pl.n_big && fused_upload(pl, &pl.d_big, big.data(), big.size(), stream)) return -1;
     const char *env_dbg = getenv("GBP_FUSED_DBG");
-    pl.args = FusedArgs{d_bp, acc_doubles, env_dbg ? atoi(env_dbg) : 0};
+    unsigned long long *d_phase = nullptr;
+#ifdef GBP_PHASE_TIMING
+    if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
+#endif
+    pl.args = FusedArgs{d_bp, acc_doubles, env_dbg ? atoi(env_dbg) : 0, d_phase};
     pl.d_blk = d_blk;
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \

@@ -72,6 +72,15 @@ struct Params {
     int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
 };
 
+// The sweep's scalar parameters, pinned to SGPRs at the top of every tile: left alone, the compiler copies the ten doubles
+// into VGPR pairs once outside the persistent loop (a VALU instruction takes one scalar operand) and then keeps 20 registers
+// busy -- or spills them -- through the whole tile.  After this, each use moves its operand in where it is needed.
+GBP_DEV void pin_scalars(Params &q)
+{
+    asm volatile("" : "+s"(q.K.fx), "+s"(q.K.fy), "+s"(q.K.cx), "+s"(q.K.cy));
+    asm volatile("" : "+s"(q.sigma2), "+s"(q.nstds), "+s"(q.beta), "+s"(q.eta_damping));
+}
+
 // element (slot, row) of a tile block: rows are stored in PAIRS, [row/2][lane][row%2], so that a lane owns 16 contiguous
 // bytes per pair and the fused sweep moves a tile with half the vector-memory instructions (a wave can have at most
 // 64 of them outstanding; 8-byte rows needed ~130 per tile)
@@ -244,6 +253,27 @@ GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], d
     for (int i = 0; i < 6; ++i) eta[i] = v[CAM_ETA + i];
 #pragma unroll
     for (int i = 0; i < 21; ++i) lam[i] = v[CAM_LAM + i];
+}
+
+// the same record in two gathers: mean | eta (what the relinearisation test and the linearisation need) and Lambda (needed
+// only when the cavity is formed) -- the second can be issued later, when fewer registers are live
+GBP_DEV void load_cam_head(const double *__restrict__ rec, double (&eta)[6], double (&mu)[6])
+{
+    const double2 *r2 = reinterpret_cast<const double2 *>(rec);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const double2 t = r2[i]; mu[2 * i] = t.x; mu[2 * i + 1] = t.y; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const double2 t = r2[3 + i]; eta[2 * i] = t.x; eta[2 * i + 1] = t.y; }
+}
+
+GBP_DEV void load_cam_lam(const double *__restrict__ rec, double (&lam)[21])
+{
+    const double2 *r2 = reinterpret_cast<const double2 *>(rec + CAM_LAM);
+    double v[22];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) { const double2 t = r2[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+#pragma unroll
+    for (int i = 0; i < 21; ++i) lam[i] = v[i];
 }
 
 // slot -> (valid, camera, landmark) through the tile table and the meta word

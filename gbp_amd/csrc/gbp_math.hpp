@@ -149,18 +149,33 @@ struct Rot {
 // Payne-Hanek path whose registers count against every lane even though axis-angle norms are O(1)):
 // Cody-Waite reduction by pi/2 in three parts (exact products through fma; full accuracy for theta < ~1e9, degrading
 // gracefully beyond), then the classic minimax kernels on [-pi/4, pi/4] (max error < 1 ulp).
+// A double literal that is not an inline constant needs a register pair; left to itself the compiler parks every one of
+// them in VGPRs outside the persistent loop of the fused sweep (20 registers held -- and spilled -- through the whole tile).
+// Born in SGPRs at the point of use they cost two s_mov each and no vector register (a VALU op takes one scalar operand).
+GBP_DEV double sconst(double c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
 GBP_DEV void sincos_theta(double x, double &sn, double &cs)
 {
-    const double n = rint(x * 6.36619772367581382433e-01);           // 2/pi
-    double r = fma(n, -1.5707963267948966e+00, x);
-    r = fma(n, -6.123233995736766e-17, r);
-    r = fma(n, 1.4973849048591698e-33, r);
+    const double n = rint(x * sconst(6.36619772367581382433e-01));           // 2/pi
+    double r = fma(n, sconst(-1.5707963267948966e+00), x);
+    r = fma(n, sconst(-6.123233995736766e-17), r);
+    r = fma(n, sconst(1.4973849048591698e-33), r);
     const double z = r * r;
     // sin(r) = r + r^3 (S1 + z (S2 + ...)),  cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
-    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
-    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    double ps = fma(z, sconst(1.58969099521155010221e-10), sconst(-2.50507602534068634195e-08));
+    ps = fma(z, ps, sconst(2.75573137070700676789e-06));
+    ps = fma(z, ps, sconst(-1.98412698298579493134e-04));
+    ps = fma(z, ps, sconst(8.33333333332248946124e-03));
+    ps = fma(z, ps, sconst(-1.66666666666666324348e-01));
+    double pc = fma(z, sconst(-1.13596475577881948265e-11), sconst(2.08757232129817482790e-09));
+    pc = fma(z, pc, sconst(-2.75573143513906633035e-07));
+    pc = fma(z, pc, sconst(2.48015872894767294178e-05));
+    pc = fma(z, pc, sconst(-1.38888888888741095749e-03));
+    pc = fma(z, pc, sconst(4.16666666666666019037e-02));
     const double s0 = fma(r * z, ps, r);
     const double c0 = fma(z * z, pc, fma(z, -0.5, 1.0));
     const int q = (int)n & 3;

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Where the waves of the fused sweep spend their time: builds libgbp_hip.so with -DGBP_PHASE_TIMING into tools/ (the product
+build has none of this code), runs the 1M-factor graph and prints, per phase of the persistent loop, the share of the
+wave-time (mean over the 2048 waves of the last sweep).  Run on the GPU box.
+
+    python tools/phase_profile.py [--build-only]
+"""
+import os, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__)); REPO = os.path.dirname(HERE)
+LIB = os.path.join(HERE, 'libgbp_phase.so')
+NAMES = ['ticket+descriptor', 'issue stream loads', 'lmk beliefs of prev tile (LDS)', 'wait streams', 'camera gather', 'lmk records via LDS',
+         'maths', 'stores issued', 'wait accumulation turn', 'accumulate + loop']
+if not os.path.exists(LIB) or '--build-only' in sys.argv:
+    csrc = os.path.join(REPO, 'gbp_amd', 'csrc')
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DGBP_PHASE_TIMING',
+                           '-o', LIB, 'gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip'], cwd=csrc)
+    if '--build-only' in sys.argv:
+        sys.exit(0)
+os.environ['GBP_HIP_LIB'] = LIB
+sys.path.insert(0, REPO)
+import ctypes as ct
+import numpy as np
+from gbp_amd import _capi
+from gbp_amd.engine import BAEngine
+from gbp_amd.synthetic import make_synthetic
+p = make_synthetic(n_cams=500, n_lmks=int(os.environ.get('LMKS', 100_000)), obs_per_lmk=10, seed=0)
+e = BAEngine.from_problem(p)
+e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(60); e.sync()
+nr, nc = ct.c_int32(), ct.c_int32()
+_capi.check(e._lib.gbp_ba_phase_profile(e._h, None, 0, ct.byref(nr), ct.byref(nc)))
+out = np.zeros((nr.value, nc.value), dtype=np.uint64)
+_capi.check(e._lib.gbp_ba_phase_profile(e._h, out.ctypes.data_as(ct.c_void_p), nr.value, ct.byref(nr), ct.byref(nc)))
+tot = out.sum(axis=1).astype(np.float64)
+print(f"waves {nr.value}; ticks per wave: mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f} (s_memtime ticks)")
+share = out.astype(np.float64).sum(axis=0) / tot.sum()
+for n, s, m in zip(NAMES, share, out.astype(np.float64).mean(axis=0)):
+    print(f"  {n:34s} {100 * s:5.1f} %   {m:9.0f} ticks/wave")
