@@ -1414,7 +1414,7 @@ int gbp_ba_fused_max_cams(void)
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks)
 {
     if (!h) return fail(GBP_EINVAL, "null handle");
-    if (fused_path) *fused_path = h->fused.enabled ? 1 : 0;
+    if (fused_path) *fused_path = h->fused.enabled ? h->fused.n_groups : 0;
     if (n_tiles) *n_tiles = h->p.T;
     if (n_blocks) *n_blocks = h->fused.n_blocks;
     return GBP_OK;

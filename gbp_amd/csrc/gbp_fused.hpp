@@ -34,7 +34,8 @@
 //
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
-// (C > 516) the plan stays disabled and the general sweep runs.
+// (C > 516) the cameras are split into up to three groups: the sweep adds up the first, k_cam_pass the others; beyond that the
+// plan stays disabled and the general sweep runs.
 #pragma once
 #include "gbp_kernels.hpp"
 #include <cstdint>
@@ -52,7 +53,8 @@ static_assert(TILE_LMKS * LREC <= WAVE_LDS_DOUBLES, "landmark records of a tile 
 
 struct FusedArgs {
     double *block_partials;     // [C][n_blocks][27]
-    int acc_doubles;            // C*27
+    int acc_doubles;            // cameras of the group * 27
+    int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase
     unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
 };
@@ -250,9 +252,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
+        const int cloc = cam - a.cam_base;                 // (cameras of later groups are added up by k_cam_pass)
+        const bool mine = active && (unsigned)cloc < (unsigned)a.cam_count;
         for (int r = 0; r <= maxrank; ++r) {
-            if (active && rank == r && !(a.dbg & 2)) {     // one lane per camera in a round: ds_add_f64 is a plain RMW here
-                double *dst = acc + cam * 27;
+            if (mine && rank == r && !(a.dbg & 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
+                double *dst = acc + cloc * 27;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) unsafeAtomicAdd(dst + k, eC[k]);
 #pragma unroll
@@ -269,7 +273,75 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
         const int c = i / 27, k = i - c * 27;
-        a.block_partials[((size_t)c * gridDim.x + blockIdx.x) * 27 + k] = acc[i];
+        a.block_partials[((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * 27 + k] = acc[i];
+    }
+}
+
+// More cameras than one LDS table holds (C > 516): the sweep above adds up the messages to the first group of cameras; one
+// launch of this kernel per further group adds up the rest.  The message to the camera is rebuilt from what the sweep has just
+// stored -- eta = Jc^T q_C, Lambda = Jc^T W Jc with Jc at the factor's linearisation point (14 doubles per factor) -- instead
+// of travelling through a camera-major staging buffer (27 doubles written + read, scattered: the general sweep).  Same tile
+// walk, same in-order accumulation by (workgroup, tile, rank): the sums are bitwise those a single table would give.
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a, const int4 *__restrict__ tiles,
+                                                                        const int *__restrict__ blk_begin)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *acc = smem;
+    int *ctl = reinterpret_cast<int *>(smem + ((a.acc_doubles + 1) & ~1));
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
+    __syncthreads();
+    const int tb = blk_begin[blockIdx.x], ntl = blk_begin[blockIdx.x + 1] - tb;
+    for (;;) {
+        int ti = 0;
+        if (lane == 0) ti = atomicAdd(&ctl[0], 1);
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        if (ti >= ntl) break;
+        const int t = tb + ti;
+        const int4 td = tiles[t];
+        const int slot = t * WTILE + lane;
+        const unsigned meta = p.meta[slot];
+        const int st = p.state[slot];
+        const int cloc = (int)(meta >> META_LMK_BITS) - a.cam_base;
+        const bool mine = lane < td.z && (unsigned)cloc < (unsigned)a.cam_count;
+        double x0[9], qC[2], WC[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) qC[k] = p.msg[msg_at(slot, ROW_QC + k)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
+        double eC[6], MC[21];
+        if (mine) {
+            double Jc[2][6], Jl[2][3], h[2];
+            linearise(x0, p.K, Jc, Jl, h);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) eC[k] = Jc[0][k] * qC[0] + Jc[1][k] * qC[1];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) MC[k] = 0.0;
+            rank2_update<6>(MC, Jc[0], Jc[1], WC, 1.0);
+        }
+        while (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ti) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+        const int rank = state_rank(st);
+        for (int r = 0; r <= td.w; ++r) {
+            if (mine && rank == r) {
+                double *dst = acc + cloc * 27;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) unsafeAtomicAdd(dst + k, eC[k]);
+#pragma unroll
+                for (int k = 0; k < 21; ++k) unsafeAtomicAdd(dst + 6 + k, MC[k]);
+            }
+        }
+        wave_lds_sync();
+        if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
+        const int c = i / 27, k = i - c * 27;
+        a.block_partials[((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * 27 + k] = acc[i];
     }
 }
 
@@ -326,8 +398,12 @@ __global__ __launch_bounds__(BLOCK) void k_cam_reduce_tree(Params p, const doubl
 
 // ------------------------------------------------------------------------------------ host --
 
+constexpr int MAX_CAM_GROUPS = 2;                   // a third group already costs more than the staged general sweep (measured, C = 1500)
+constexpr int PASS_WAVES = 16;                      // k_cam_pass keeps little state per lane: four waves per SIMD
+
 struct FusedPlan {
     bool enabled = false;
+    int n_groups = 0, group_cams = 0;               // camera groups of at most group_cams cameras (1 group: everything in one launch)
     int n_blocks = 0, n_big = 0;
     size_t shmem = 0;
     FusedArgs args{};
@@ -374,15 +450,19 @@ inline int fused_max_cams()
 // Workgroup tile ranges + per-workgroup camera tables; `big` = landmarks larger than a tile.
 inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
 {
-    const int acc_doubles = p.C * 27;
-    const size_t shmem = fused_shmem(p.C);
-    if (shmem > (size_t)LDS_BYTES || p.F == 0 || p.C == 0 || p.T == 0) return 0;      // general sweep instead
+    if (p.F == 0 || p.C == 0 || p.T == 0) return 0;
+    const int cmax = fused_max_cams();
+    pl.n_groups = (p.C + cmax - 1) / cmax;
+    if (pl.n_groups > MAX_CAM_GROUPS) return 0;                                        // general sweep instead
+    pl.group_cams = (p.C + pl.n_groups - 1) / pl.n_groups;
+    const int acc_doubles = pl.group_cams * 27;
+    const size_t shmem = fused_shmem(pl.group_cams);
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     std::vector<int32_t> blk((size_t)pl.n_blocks + 1);
     for (int b = 0; b <= pl.n_blocks; ++b) blk[b] = (int32_t)((int64_t)b * p.T / pl.n_blocks);
     int *d_blk = nullptr; double *d_bp = nullptr;
     if (fused_upload(pl, &d_blk, blk.data(), blk.size(), stream)) return -1;
-    if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * acc_doubles, stream)) return -1;
+    if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * 27, stream)) return -1;
     pl.n_big = (int)big.size();
     if (pl.n_big && fused_upload(pl, &pl.d_big, big.data(), big.size(), stream)) return -1;
     const char *env_dbg = getenv("GBP_FUSED_DBG");
@@ -390,13 +470,14 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 #ifdef GBP_PHASE_TIMING
     if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
 #endif
-    pl.args = FusedArgs{d_bp, acc_doubles, env_dbg ? atoi(env_dbg) : 0, d_phase};
+    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), env_dbg ? atoi(env_dbg) : 0, d_phase};
     pl.d_blk = d_blk;
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
                             (int)shmem) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
+    GBP_SET_SHMEM((k_cam_pass<PASS_WAVES>))
 #undef GBP_SET_SHMEM
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
@@ -418,6 +499,13 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles, pl.d_blk); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
+    for (int g = 1; g < pl.n_groups; ++g) {                 // the messages to the cameras of the further groups (C > 516)
+        FusedArgs ag = pl.args;
+        ag.cam_base = g * pl.group_cams;
+        ag.cam_count = std::min(p.C - ag.cam_base, pl.group_cams);
+        ag.acc_doubles = ag.cam_count * 27;
+        hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.shmem, stream, p, ag, p.tiles, pl.d_blk);
+    }
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
     const size_t red_shmem = sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27);
     hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(BLOCK), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);

@@ -339,4 +339,4 @@ class BAEngine:
     def info(self):
         a, b, c = ct.c_int32(), ct.c_int32(), ct.c_int32()
         check(self._lib.gbp_ba_info(self._h, ct.byref(a), ct.byref(b), ct.byref(c)))
-        return dict(fused=bool(a.value), n_tiles=b.value, n_blocks=c.value)
+        return dict(fused=bool(a.value), cam_groups=a.value, n_tiles=b.value, n_blocks=c.value)

@@ -29,11 +29,17 @@ def test_camera_count_at_the_lds_boundary(oracle_mod):
     from gbp_amd import _capi
     cmax = _capi.load().gbp_ba_fused_max_cams()
     assert 256 <= cmax <= 758                       # 160 KB / 216 B per camera, minus the per-wave scratch
-    for C, fused in ((cmax, True), (cmax + 1, False)):
-        prob = make_synthetic(n_cams=C, n_lmks=700, obs_per_lmk=6, seed=21)
-        gap, o, e = run_pair(oracle_mod, prob)
-        assert e.info()['fused'] == fused, (C, e.info())
+    # one table / two camera groups (k_cam_pass) / three groups would be needed: the staged general sweep
+    for C, groups in ((cmax, 1), (cmax + 1, 2), (2 * cmax, 2), (2 * cmax + 1, 0)):
+        prob = make_synthetic(n_cams=C, n_lmks=900, obs_per_lmk=6, seed=21)
+        gap, o, e = run_pair(oracle_mod, prob, n_sweeps=10)
+        assert e.info()['cam_groups'] == groups, (C, e.info())
         assert gap < BELIEF_TOL, (C, gap)
+        for a, b in zip(e.messages(), o.messages()):
+            assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+        if groups > 1:                                  # the grouped sums are the single-table sums: same as the general sweep to rounding
+            gap2, _, e2 = run_pair(oracle_mod, prob, n_sweeps=10, fused=False)
+            assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), e2.beliefs())) < 1e-7
 
 
 def with_landmarks(p, degrees, seed=5):

@@ -424,20 +424,22 @@ def test_full_size_properties_1m_factors(eng_mod):
 
 
 def test_many_cameras_fall_back_to_the_general_sweep(eng_mod, oracle_mod):
-    """C = 700 cameras: the camera table of the fused sweep (C x 27 doubles) no longer fits the LDS, so the engine must
-    run the tile-based general sweep on its own (k_factor_tile + camera-major staging) -- same results, incl. one
-    landmark larger than a tile (its belief comes from k_lmk_belief_list)."""
+    """C = 700 cameras: the camera table of the fused sweep (C x 27 doubles) no longer fits the LDS, so the engine splits
+    the cameras into two groups (fused sweep + one k_cam_pass launch); forced to the tile-based general sweep
+    (k_factor_tile + camera-major staging) it must give the same results, incl. one landmark larger than a tile (its belief
+    comes from k_lmk_belief_list)."""
     big = make_synthetic(n_cams=700, n_lmks=1, obs_per_lmk=90, seed=8)
     q = make_synthetic(n_cams=700, n_lmks=900, obs_per_lmk=6, seed=9)
     prob = BAProblem(K=q.K, cam_means=q.cam_means, lmk_means=np.concatenate([big.lmk_means[:1], q.lmk_means]),
                      meas=np.concatenate([big.meas, q.meas]), cam_idx=np.concatenate([big.cam_idx, q.cam_idx]),
                      lmk_idx=np.concatenate([big.lmk_idx, q.lmk_idx + 1]).astype(np.int32))
-    gap, o, e = oracle_vs_engine(eng_mod, oracle_mod, prob, 20, True)
-    assert not e.info()['fused']
-    assert gap < BELIEF_TOL, gap
-    assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
-    for a, b in zip(e.messages(), o.messages()):
-        assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < MSG_TOL
+    for fused, groups in ((True, 2), (False, 0)):
+        gap, o, e = oracle_vs_engine(eng_mod, oracle_mod, prob, 20, fused)
+        assert e.info()['cam_groups'] == groups
+        assert gap < BELIEF_TOL, gap
+        assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
+        for a, b in zip(e.messages(), o.messages()):
+            assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < MSG_TOL
 
 
 def test_streaming_means_snapshot(eng_mod):
