@@ -41,6 +41,43 @@ class _Lazy:
         return list(self) + list(other)
 
 
+class _Concat:
+    """cam_nodes followed by lmk_nodes without materialising either (graph.var_nodes, gbp_ba.py:147)."""
+
+    def __init__(self, a, b):
+        self._a, self._b = a, b
+
+    def __len__(self):
+        return len(self._a) + len(self._b)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self._a[i] if i < len(self._a) else self._b[i - len(self._a)]
+
+    def __iter__(self):
+        yield from self._a
+        yield from self._b
+
+
+class _PriorProxy(NdimGaussian):
+    """node.prior: reads come from the device state; assigning .eta / .lam (what scripts written for the reference do,
+    e.g. ndim_posegraph.py:51-52) is kept on the host and uploaded before the next device call."""
+
+    def __init__(self, graph, kind, index, eta, lam):
+        object.__setattr__(self, '_bind', None)
+        super().__init__(len(eta), eta, lam)
+        object.__setattr__(self, '_bind', (graph, kind, index))
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        bind = self.__dict__.get('_bind')
+        if bind is not None and name in ('eta', 'lam'):
+            bind[0]._write_prior(bind[1], bind[2], name, value)
+
+
 class _VariableView:
     """VariableNode surface (gbp.py:156-198) of one camera or landmark."""
 
@@ -71,7 +108,7 @@ class _VariableView:
     @property
     def prior(self):
         b = self._g._priors()
-        return NdimGaussian(self.dofs, b[2 * self._kind][self._i], b[2 * self._kind + 1][self._i])
+        return _PriorProxy(self._g, self._kind, self._i, b[2 * self._kind][self._i], b[2 * self._kind + 1][self._i])
 
     @property
     def adj_factors(self):
@@ -124,11 +161,11 @@ class _FactorView:
 
     @property
     def measurement(self):
-        return self._g._engine.factors(self.factorID, 1, dense=False)['z'][0]
+        return self._g._lin(self.factorID)['z']
 
     @property
     def linpoint(self):
-        return self._g._engine.factors(self.factorID, 1, dense=False)['linpoint'][0]
+        return self._g._lin(self.factorID)['linpoint']
 
     @property
     def factor(self):
@@ -171,9 +208,10 @@ class BAFactorGraph:
         self.cam_nodes = _Lazy(self._C, lambda i: _VariableView(self, 0, i))
         self.lmk_nodes = _Lazy(self._L, lambda i: _VariableView(self, 1, i))
         self.factors = _Lazy(self._F, lambda f: _FactorView(self, f))
-        self.var_nodes = self.cam_nodes + self.lmk_nodes if self._C + self._L <= 100000 else None
+        self.var_nodes = _Concat(self.cam_nodes, self.lmk_nodes)
         self.n_var_nodes, self.n_factor_nodes, self.n_edges = self._C + self._L, self._F, 2 * self._F
         self._cache, self._iters_host, self._iters_dirty = {}, None, False
+        self._priors_host = None                          # priors written from Python, waiting to go to the device
         self._adj = None
 
     # ---- host mirrors ------------------------------------------------------------------------------------------
@@ -193,7 +231,25 @@ class BAFactorGraph:
         return self._cached('bel', self._engine.beliefs)
 
     def _priors(self):
+        if self._priors_host is not None:
+            return self._priors_host
         return self._cached('pri', self._engine.priors)
+
+    def _write_prior(self, kind, i, name, value):
+        if self._priors_host is None:
+            self._priors_host = [np.array(a) for a in self._engine.priors()]
+        self._priors_host[2 * kind + (name == 'lam')][i] = np.asarray(value, dtype=np.float64)
+
+    _LIN_MIRROR_MAX = 200_000      # factors: up to here measurement / linpoint reads share one host mirror of all factors
+
+    def _lin(self, f):
+        """Factor.measurement / Factor.linpoint: a mirror of all factors for graphs a Python loop can walk, a one-factor
+        device gather (gbp_ba_get_factors moves only the requested range) above that."""
+        if self._F <= self._LIN_MIRROR_MAX:
+            d = self._cached('lin', lambda: self._engine.factors(dense=False))
+            return dict(z=d['z'][f], linpoint=d['linpoint'][f])
+        d = self._engine.factors(f, 1, dense=False)
+        return dict(z=d['z'][0], linpoint=d['linpoint'][0])
 
     def _covs(self):
         return self._cached('cov', self._engine.covariances)
@@ -211,6 +267,10 @@ class BAFactorGraph:
         self._iters_dirty = True
 
     def _flush(self):
+        if self._priors_host is not None:
+            self._engine.set_priors(*self._priors_host)
+            self._priors_host = None
+            self._cache.pop('pri', None)
         if self._iters_dirty:
             it = self._iters_host
             if np.all(it == it[0]):
@@ -257,12 +317,72 @@ class BAFactorGraph:
         self._engine.iterate(n, robustify=robustify, local_relin=local_relin)
         self._invalidate()
 
+    # The reference lets a caller run the four stages of a sweep one by one (gbp.py:46-84).  On the device they are ONE
+    # kernel -- a factor's messages are formed in the registers that hold its fresh linearisation -- so the stage-wise entry
+    # points say so instead of silently doing something else.  synchronous_iteration(robustify=, local_relin=) covers every
+    # combination the reference's own scripts use.
+    def _one_kernel(self, name):
+        raise NotImplementedError(
+            f"BAFactorGraph.{name}() is not available on the device graph: robustify / relinearise / messages / beliefs run as "
+            f"one fused kernel; call synchronous_iteration(robustify=..., local_relin=...) (gbp.py:86-92) instead")
+
+    def robustify_all_factors(self):
+        self._one_kernel('robustify_all_factors')
+
+    def relinearise_factors(self):
+        self._one_kernel('relinearise_factors')
+
+    def compute_all_messages(self, local_relin=True):
+        self._one_kernel('compute_all_messages')
+
+    def compute_all_factors(self):
+        """gbp.py:60-62 relinearises every factor at the current belief means and keeps the messages.  The device stores a
+        message as coefficients in the rows of its factor's Jacobian, so moving the linearisation point without a sweep
+        would change the messages; factors are linearised at the file means by create_ba_graph and at the belief means
+        by the sweep's own relinearisation test."""
+        self._one_kernel('compute_all_factors')
+
+    def joint_distribution_inf(self):
+        """gbp.py:94-134: joint (eta, Lambda) over all variables from the priors and the factors at their current
+        linearisation points -- dense, for graphs small enough to solve in batch."""
+        n = 6 * self._C + 3 * self._L
+        if n > 20000:
+            raise MemoryError(f"the dense joint of {n} scalar variables does not fit a batch solve")
+        self._flush()
+        eta, lam = np.zeros(n), np.zeros((n, n))
+        ce, cl, le, ll = self._priors()
+        for c in range(self._C):
+            eta[6 * c:6 * c + 6] += ce[c]; lam[6 * c:6 * c + 6, 6 * c:6 * c + 6] += cl[c]
+        o = 6 * self._C
+        for l in range(self._L):
+            eta[o + 3 * l:o + 3 * l + 3] += le[l]; lam[o + 3 * l:o + 3 * l + 3, o + 3 * l:o + 3 * l + 3] += ll[l]
+        fac = self._engine.factors()
+        for f in range(self._F):
+            a, b = 6 * int(self._cam_of[f]), o + 3 * int(self._lmk_of[f])
+            fe, fl = fac['eta'][f], fac['lam'][f]
+            eta[a:a + 6] += fe[:6]; eta[b:b + 3] += fe[6:]
+            lam[a:a + 6, a:a + 6] += fl[:6, :6]; lam[a:a + 6, b:b + 3] += fl[:6, 6:]
+            lam[b:b + 3, a:a + 6] += fl[6:, :6]; lam[b:b + 3, b:b + 3] += fl[6:, 6:]
+        return eta, lam
+
+    def joint_distribution_cov(self):
+        eta, lam = self.joint_distribution_inf()
+        sigma = np.linalg.inv(lam)
+        return sigma @ eta, sigma
+
     # ---- diagnostics (gbp_ba.py:54-69, gbp.py:36-44) -----------------------------------------------------------
     def are(self):
+        self._flush()
         return self._engine.are()
 
     def energy(self):
+        self._flush()
         return self._engine.energy()
+
+    def count_relinearising(self):
+        """ba.py:96-99 (`sum(factor.iters_since_relin == 0 for factor in graph.factors)`) as one device reduction."""
+        self._flush()
+        return self._engine.count_relinearising()
 
     def compute_residuals(self):
         out = []

@@ -62,3 +62,42 @@ def test_ba_script_sequence(compat_path):
     assert len(graph.cam_nodes[3].adj_factors) == int((graph._cam_of == 3).sum())
     assert viewer.n_updates == 30 and len(viewer.landmarks) == 1216
     assert abs(f0.reprojection_err() - np.linalg.norm(f0.compute_residual())) < 1e-12
+
+
+def test_factor_graph_surface_of_the_device_graph(compat_path):
+    """What scripts written against gbp.FactorGraph may touch beyond ba.py's own sequence: var_nodes is always
+    a sequence, priors can be assigned through the node views, the batch joint is available, and the stage-wise methods
+    that one fused kernel cannot honour say so."""
+    from gbp import gbp_ba
+    configs = dict(gauss_noise_std=2, loss=None, Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8,
+                   eta_damping=0.4, prior_std_weaker_factor=50.0)
+    graph = gbp_ba.create_ba_graph(os.path.join(DATA, 'fr1desk_vsmall.txt'), configs)
+    assert len(graph.var_nodes) == 650 and graph.var_nodes[0] is graph.cam_nodes[0] and graph.var_nodes[10] is graph.lmk_nodes[0]
+    assert sum(1 for _ in graph.var_nodes) == 650 and graph.var_nodes[-1] is graph.lmk_nodes[639]
+    graph.generate_priors_var(weaker_factor=50.0)
+    # writes through node.prior reach the device before the next call
+    v = graph.lmk_nodes[5]
+    lam0 = v.prior.lam.copy()
+    v.prior.lam = 3.0 * lam0
+    v.prior.eta = 3.0 * v.prior.eta
+    assert np.allclose(graph.lmk_nodes[5].prior.lam, 3.0 * lam0)            # visible at once on the host side
+    graph.update_all_beliefs()
+    assert np.allclose(graph._engine.priors()[3][5], 3.0 * lam0)            # ... and on the device after the flush
+    assert np.allclose(graph.lmk_nodes[5].belief.lam, 3.0 * lam0)           # no messages yet: belief = prior
+    with pytest.raises(AttributeError):
+        v.mu = np.zeros(3)
+    # batch solution of the linearised problem (gbp.py:94-144) against the same thing assembled from the views
+    eta, lam = graph.joint_distribution_inf()
+    assert eta.shape == (60 + 1920,) and np.allclose(lam, lam.T)
+    f7 = graph.factors[7]
+    a, b = 6 * f7.adj_vIDs[0], 60 + 3 * (f7.adj_vIDs[1] - 10)
+    blk = sum(graph.factors[int(k)].factor.lam[:6, :6] for k in np.nonzero(graph._cam_of == f7.adj_vIDs[0])[0])
+    assert np.allclose(lam[a:a + 6, a:a + 6], blk + graph.cam_nodes[f7.adj_vIDs[0]].prior.lam, rtol=1e-10)
+    mu, sigma = graph.joint_distribution_cov()
+    assert np.isfinite(mu).all() and mu.shape == eta.shape
+    for name in ('robustify_all_factors', 'relinearise_factors', 'compute_all_messages', 'compute_all_factors'):
+        with pytest.raises(NotImplementedError):
+            getattr(graph, name)()
+    graph.synchronous_iteration(robustify=True, local_relin=True)
+    assert graph.count_relinearising() == sum(1 for f in graph.factors if f.iters_since_relin == 0)
+    assert np.array_equal(graph.factors[3].linpoint, graph._engine.factors(3, 1, dense=False)['linpoint'][0])
