@@ -97,6 +97,26 @@ def cpu_baseline(problem, budget_s=20.0):
             "value_1thread": 1.0 / dt1, "us_per_factor_iter_1thread": dt1 / problem.n_factors * 1e6}
 
 
+def cpu_baseline_numpy(problem, budget_s=15.0):
+    """the numpy restatement with the reference's cost model (one Python object per factor, ~40 numpy calls per
+    factor and sweep) at 1 thread -- only sensible on the small graphs of BASELINE configs 2-3."""
+    from oracle.numpy_ba import NumpyBA
+    n = NumpyBA(problem)
+    n.generate_priors_var(50.0)
+    n.update_all_beliefs()
+    t0 = time.perf_counter()
+    n.iterate(1)
+    dt = time.perf_counter() - t0
+    k = int(max(0, min(5, (budget_s - dt) // max(dt, 1e-3))))
+    if k:
+        t0 = time.perf_counter()
+        n.iterate(k)
+        dt = (time.perf_counter() - t0) / k
+    return {"value": 1.0 / dt, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": f"{max(k, 1)} whole sweeps of the same {problem.n_factors}-factor graph, object-per-factor numpy graph (oracle/numpy_ba.py)",
+            "us_per_factor_iter": dt / problem.n_factors * 1e6}
+
+
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_hbm_traffic.json)."""
     import glob
@@ -295,6 +315,8 @@ def main():
             out["dry_run"] = True
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(problem)
+            if args.bal and F <= 50_000:
+                out["cpu_baseline_numpy"] = cpu_baseline_numpy(problem)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

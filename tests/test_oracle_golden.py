@@ -57,6 +57,20 @@ def test_g1b_edge_rotations(oracle_mod):
         assert np.abs(J2 - J).max() <= 1e-12 * np.abs(J).max()
 
 
+def test_numpy_restatement_against_g4(oracle_mod):
+    """The object-per-factor numpy graph (oracle/numpy_ba.py: bench.py's second CPU baseline on configs 2-3) follows the
+    reference trace on fr1desk_vsmall: ARE / energy of the first sweeps and the beliefs after 5 (fixture G4)."""
+    from oracle.numpy_ba import NumpyBA
+    g = golden('G4_trace_vsmall')
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    n = NumpyBA(p)
+    n.generate_priors_var(50.0)
+    n.update_all_beliefs()
+    ares, energies = oracle_mod.replay_ba(n, 5, diagnostics=True)
+    assert np.allclose(ares, g['are'][:5], rtol=1e-7) and np.allclose(energies, g['energy'][:5], rtol=1e-6)
+    assert belief_gap(n.beliefs(), g, 'it5_') < 1e-6
+
+
 def test_g2_reader_and_initial_factors(oracle_mod):
     g = golden('G2_init_factors_vsmall')
     p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
