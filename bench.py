@@ -160,6 +160,7 @@ def main():
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-batch', action='store_true', help='one timed batch only (profiling runs)')
+    ap.add_argument('--sharded', action='store_true', help='take the N > 1 code path (process group, ShardedBA, RCCL exchange forced) even with one rank')
     ap.add_argument('--python-loop', action='store_true', help='N > 1: drive the sweeps from Python (shard_begin / all_gather / shard_end)')
     ap.add_argument('--dump-sweeps', default=None, help='write the per-sweep kernel times (ms) and relinearisation counts of the instrumented replay to this .npz')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend of the side channel (tests: gloo)')
@@ -170,6 +171,12 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+
+    # Only the JSON line may reach stdout: native libraries (RCCL prints a version banner at communicator creation) write to
+    # file descriptor 1 directly, so the descriptor itself is pointed at stderr and the result goes out through a saved copy.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
@@ -194,7 +201,7 @@ def main():
     F, L, C = problem.n_factors, problem.n_lmks, problem.n_cams
 
     dist = None
-    if world > 1 or dry:
+    if world > 1 or dry or args.sharded:
         import torch.distributed as dist
         from gbp_amd.sharded import ShardedBA
         if dry:
@@ -203,8 +210,11 @@ def main():
             dist.init_process_group(args.backend)
             graph = ShardedBA(problem, engine_factory=getattr(importlib.import_module(mod), fn))
         else:
+            if 'MASTER_ADDR' not in os.environ:                     # --sharded without torchrun: a one-rank group of our own
+                os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
             dist.init_process_group(args.backend, device_id=torch.device('cuda', local_rank))
-            graph = ShardedBA(problem, device=local_rank, fused=not args.no_fused, library_loop=not args.python_loop)
+            graph = ShardedBA(problem, device=local_rank, fused=not args.no_fused, library_loop=not args.python_loop,
+                              always_exchange=args.sharded)
     else:
         from gbp_amd.engine import BAEngine
         graph = BAEngine.from_problem(problem, device=local_rank, fused=not args.no_fused)
@@ -303,7 +313,7 @@ def main():
                        "n_cams": C, "n_lmks": L, "n_factors": F,
                        "parallelism": f"landmark-sharded x{world}, RCCL all-gather of camera partial sums per sweep" if world > 1 else "single GPU",
                        "sweep": "fused" if fused else "general",
-                       "loop": ("python" if (args.python_loop or dry) else "in-library") if world > 1 else "gbp_ba_iterate"},
+                       "loop": ("python" if (args.python_loop or dry) else "in-library") if (world > 1 or args.sharded) else "gbp_ba_iterate"},
             "timing": {"protocol": "state restored before every batch; W warm-up + K timed sweeps between barrier+synchronize; median over batches",
                        "batches": int(times.size), "timed_seconds": float(times.sum()),
                        "ms_per_step_median": dt_med / args.steps * 1e3, "ms_per_step_min": dt_min / args.steps * 1e3,
@@ -317,7 +327,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(problem)
             if args.bal and F <= 50_000:
                 out["cpu_baseline_numpy"] = cpu_baseline_numpy(problem)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         if hasattr(graph, 'close'):
