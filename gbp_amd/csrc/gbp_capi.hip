@@ -284,7 +284,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         CHK(ensure_staging(h));
         CHK(launch_factor_stage(h, robustify, local_relin));
         if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
-        if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(1024), 0, h->stream, h->p, partial);
+        if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial);
         HIPCHK(hipGetLastError());
         return GBP_OK;
     }

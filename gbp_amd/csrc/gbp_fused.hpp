@@ -55,7 +55,8 @@ struct FusedArgs {
     double *block_partials;     // [C][n_blocks][27]
     int acc_doubles;            // cameras of the group * 27
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
-    int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase
+    int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase,
+                                // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results)
     unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
 };
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         // the camera record of this tile's factors: a gather that needs `meta` (L2 hits)
         const int cam = active ? (int)(meta >> META_LMK_BITS) : 0;
         GBP_PH(3);                                         // the streams (and meta) have arrived
-        load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, clC, muC);
+        load_cam_record(p.cbel + (size_t)((a.dbg & 8) ? (cam & 7) : cam) * CAMREC, etaC, clC, muC);   // (dbg 8: what would a cheap gather buy?)
         asm volatile("" ::: "memory");
         GBP_PH(4);                                         // camera gather
 

@@ -50,7 +50,8 @@ constexpr int CAM_MU = 0, CAM_ETA = 6, CAM_LAM = 12;
 constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (camera in the LOW bits + '& 0xffffff' was
                                    // miscompiled by hipcc 7.2: the mask vanished in front of a v_mad_u64_u32 address multiply)
 constexpr int BLOCK = 256;
-constexpr int CSTAGE_ROW = 27;     // doubles per row of the camera-major staging buffer
+constexpr int CSTAGE_ROW = 20;     // doubles per row of the camera-major staging buffer: x0 9 | q_C 2 | W 3 | (xtra: remainder 6)
+constexpr int CSTAGE_USED = 14;    // ... of which the rows carry 14 unless Params::xtra is set
 
 struct Params {
     int F, T, L, C;               // factors, tiles (slots = 64 T), landmarks, cameras
@@ -65,7 +66,7 @@ struct Params {
     double *lrec;
     double *cbel, *cprior;
     const int *cptr, *cadj;
-    double *cstage;               // general sweep: [F][27] camera messages in camera-major (reference) order, or NULL
+    double *cstage;               // general sweep: [F][CSTAGE_ROW] what rebuilds the camera messages, in camera-major (reference) order, or NULL
     const int *cpos;              // slot -> row of cstage
     double *xtra;                 // [slot][9] out-of-span remainder of the message etas, or NULL (gbp_math.hpp header: only when
                                   // num_undamped_iters = 0 lets a factor be damped in the sweep it relinearises in)
@@ -317,13 +318,14 @@ GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (
 // camera table of the fused sweep does not fit the LDS (C > 516):
 //   * the landmarks a tile owns get their beliefs from the same wave (new messages through LDS, prior + sum in
 //     adj_factors order, 3x3 solve) -- no second pass over the messages (k_lmk_belief re-reads and re-linearises them);
-//   * the dense message to the camera (eta 6 | Lambda 21) is written to cstage[cpos[slot]], i.e. in the camera's own
+//   * what rebuilds the message to the camera (x0 9 | q_C 2 | W 3: eta = Jc^T q_C, Lambda = Jc^T W Jc with Jc at x0 -- 14
+//     doubles instead of the dense 27) is written to cstage[cpos[slot]], i.e. in the camera's own
 //     adj_factors order, so k_cam_partial_staged reads one contiguous run per camera instead of gathering 16-byte
 //     pieces and rebuilding Jacobians (k_cam_partial fetches 562 MB per sweep at 1M factors; this is 216 + 216 MB).
 template <int LOSS, bool XTRA>
 __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 {
-    __shared__ double wls[BLOCK / 64][WTILE * 27];          // per wave: [64][9] landmark messages, then [64][27] camera messages
+    __shared__ double wls[BLOCK / 64][WTILE * CSTAGE_ROW];  // per wave: [64][9] landmark messages, then [64][20] camera-message rows
     __shared__ int wps[BLOCK / 64][WTILE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int t = blockIdx.x * (BLOCK / 64) + wave;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     const int l0 = td.x, nl = td.y, nf = td.z;
     const bool active = lane < nf;
     const int slot = t * WTILE + lane;
-    double eCout[6], MCout[21];
+    double srow[XTRA ? CSTAGE_ROW : CSTAGE_USED];           // x0 | q_C | W (| remainder) of this lane's factor AFTER the sweep
     if (active) {
         const unsigned meta = p.meta[slot];
         const int cam = (int)(meta >> META_LMK_BITS), lmk = l0 + (int)(meta & ((1u << META_LMK_BITS) - 1u));
@@ -385,9 +387,14 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
         wp[lane] = p.cpos[slot];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eCout[k] = eCn[k];
+        for (int k = 0; k < 9; ++k) srow[k] = x0[k];
+        srow[9] = qC[0]; srow[10] = qC[1];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) MCout[k] = MCn[k];
+        for (int k = 0; k < 3; ++k) srow[11 + k] = WC[k];
+        if (XTRA) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) srow[CSTAGE_USED + k] = p.xtra[(size_t)slot * XTRA_ROW + k];
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's LDS writes are done (one wave: no barrier needed)
     if (lane < nl) {                                        // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks
@@ -407,54 +414,75 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 #pragma unroll
         for (int k = 0; k < 3; ++k) lr[LR_MU + k] = mu[k];
     }
-    // camera messages -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction
-    // (27 x 64 eight-byte pieces per tile); transposed, two factors' 216-byte runs go out per instruction
+    // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
+    // transposed, four factors' 112-byte rows (three 160-byte ones with the remainder) go out per instruction
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
+    constexpr int R = XTRA ? CSTAGE_ROW : CSTAGE_USED, PER = 64 / R;
     if (active) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wl[lane * 27 + k] = eCout[k];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) wl[lane * 27 + 6 + k] = MCout[k];
+        for (int k = 0; k < R; ++k) wl[lane * R + k] = srow[k];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-        // (padding the rows to two whole 128-byte lines did not help: the cost is the scatter itself -- every factor's row
-        //  lands in a different DRAM page -- not partial lines)
-        const int half = lane >= 27 ? 1 : 0, k = lane - 27 * half;
-        if (lane < 54) {
-            for (int f = half; f < nf; f += 2) p.cstage[(size_t)wp[f] * CSTAGE_ROW + k] = wl[f * 27 + k];
+        const int g = lane / R, k = lane - g * R;
+        if (g < PER) {
+            for (int f = g; f < nf; f += PER) p.cstage[(size_t)wp[f] * CSTAGE_ROW + k] = wl[f * R + k];
         }
     }
 }
 
-// One workgroup of 1024 threads per camera: partial[c][27] = sum of its staged messages; 37 x 27 threads stride the
-// camera's contiguous run (every 37th factor each), then 27 threads add the 37 partial sums -- fixed order, bitwise
-// reproducible, and the order inside the camera is the reference's adj_factors order.
-constexpr int STAGE_PARTS = 37;
-__global__ __launch_bounds__(1024) void k_cam_partial_staged(Params p, double *__restrict__ partial)
+// One workgroup per camera: partial[c][27] = sum of the messages of its factors, rebuilt from the staged rows (contiguous per
+// camera, in the reference's adj_factors order): every thread linearises its factors (every 256th of the run), adds their
+// eta = Jc^T q_C (+ remainder) and Lambda = Jc^T W Jc into 27 registers, then the block adds the threads up in a fixed order
+// (shuffle tree, then the four waves) -- bitwise reproducible.
+__global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *__restrict__ partial)
 {
-    __shared__ double red[STAGE_PARTS * 27];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    if (tid < STAGE_PARTS * 27) {
-        const int part = tid / 27, k = tid - part * 27;
-        const int e0 = p.cptr[c], e1 = p.cptr[c + 1];
-        double s = 0.0;
-        int e = e0 + part;
-        for (; e + 5 * STAGE_PARTS < e1; e += 6 * STAGE_PARTS) {          // six loads in flight, added in order
-            double v[6];
+    __shared__ double red[BLOCK / 64][27];
+    const int c = blockIdx.x;
+    double acc[27];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) v[j] = p.cstage[(size_t)(e + j * STAGE_PARTS) * CSTAGE_ROW + k];
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    const int e1 = p.cptr[c + 1];
+    for (int e = p.cptr[c] + threadIdx.x; e < e1; e += BLOCK) {
+        const double2 *row = reinterpret_cast<const double2 *>(p.cstage + (size_t)e * CSTAGE_ROW);
+        double v[CSTAGE_ROW];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) s += v[j];
+        for (int i = 0; i < CSTAGE_USED / 2; ++i) { const double2 t = row[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+        double x0[9], Jc[2][6], Jl[2][3], h[2], MC[21];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x0[k] = v[k];
+        linearise(x0, p.K, Jc, Jl, h);
+        const double W[3] = {v[11], v[12], v[13]};
+#pragma unroll
+        for (int k = 0; k < 21; ++k) MC[k] = 0.0;
+        rank2_update<6>(MC, Jc[0], Jc[1], W, 1.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += Jc[0][k] * v[9] + Jc[1][k] * v[10];
+        if (p.xtra) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const double2 t = row[CSTAGE_USED / 2 + i]; acc[2 * i] += t.x; acc[2 * i + 1] += t.y; }
         }
-        for (; e < e1; e += STAGE_PARTS) s += p.cstage[(size_t)e * CSTAGE_ROW + k];
-        red[tid] = s;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) acc[6 + k] += MC[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        acc[k] = v;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) red[wave][k] = acc[k];
     }
     __syncthreads();
-    if (tid < 27) {
-        double s = red[tid];
-        for (int q = 1; q < STAGE_PARTS; ++q) s += red[q * 27 + tid];
-        partial[(size_t)c * 27 + tid] = s;
+    if (threadIdx.x < 27) {
+        double s2 = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) s2 += red[w][threadIdx.x];
+        partial[(size_t)c * 27 + threadIdx.x] = s2;
     }
 }
 

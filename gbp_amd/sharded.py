@@ -117,8 +117,25 @@ class ShardedBA:
         self._gathered = self.shard.new_buffer(n * self.world)
         self.library_loop = False
         if hasattr(self.shard, 'init_comm') and library_loop:
-            self.shard.init_comm(dist, always_exchange)
-            self.library_loop = True
+            # every rank must take the same path: agree on whether the library's communicator came up everywhere, else all
+            # ranks drive the sweep from Python over the process group (slower per sweep, same results)
+            try:
+                self.shard.init_comm(dist, always_exchange)
+                ok = 1
+            except Exception as e:                          # noqa: BLE001 -- reported below, the job goes on
+                import sys
+                print(f"[gbp_amd] rank {self.rank}: in-library exchange unavailable ({e}); Python-driven loop instead", file=sys.stderr)
+                ok = 0
+            if hasattr(dist, 'device_exchange'):
+                self.library_loop = bool(ok)
+            else:
+                with self._ctx():
+                    t = self.shard.to_tensor(np.array([float(ok)]))
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                self.shard.sync()
+                self.library_loop = bool(t.cpu().numpy()[0] > 0.5)
+                if ok and not self.library_loop:
+                    self.engine.comm_destroy()
 
     # ---- set-up ---------------------------------------------------------------------------
     def generate_priors_var(self, weaker_factor=100.0):
