@@ -7,9 +7,13 @@
 //   2. sort_pairs             stable by camera      -> reference factor r = file row ref_file[r]       (skipped when sorted)
 //      k_lower_bounds         camera CSR offsets cptr
 //   3. sort_pairs             stable by landmark    -> landmark-major list lm2ref (adj_factors order), offsets lptr
-//   4. tile packing           a next-fit walk over the L landmark degrees (64 slots / 24 landmarks per tile, landmarks above 64
-//                             factors cut into chunk tiles).  The walk is sequential in L, not F: it runs on the host over the
-//                             downloaded lptr (0.4 MB at 100k landmarks) and uploads the tile table (T x 16 B)
+//   4. tile packing           next-fit over the landmark degrees (64 slots / 24 landmarks per tile, landmarks above 64 factors
+//                             cut into chunk tiles).  Next-fit is a chain -- where a tile starts depends on where the previous one
+//                             ended -- so it is done as LIST RANKING: k_pack_next gives every landmark the landmark the next
+//                             tile would start at IF a tile started here, pointer doubling (k_pack_double) builds 2^k-hop jump
+//                             tables with the number of tiles they cross, and k_pack_mark walks them from the top level down,
+//                             handing every landmark that really starts a tile its tile index; k_pack_emit writes the tile
+//                             table and the slot ranges.  Two ints (tile count, over-sized landmarks) come back to the host
 //   5. k_build_tiles          one wave per tile: every slot finds its factor, writes x0 | z | variance, meta, state (with the
 //                             factor's rank among the same-camera factors of its tile) and both directions of the
 //                             reference-id <-> slot map
@@ -60,6 +64,70 @@ __global__ __launch_bounds__(BLOCK) void k_lower_bounds(const int *__restrict__ 
         if (keys[mid] < v) lo = mid + 1; else hi = mid;
     }
     ptr[v] = lo;
+}
+
+// ---- tile packing as list ranking ------------------------------------------------------------------------------------------
+// nxt[l] = first landmark of the tile after the one that would start at l; w[l] = tiles that start at l (1, or the chunk count of an
+// over-sized landmark).  Entry L is the end of the chain.
+__global__ __launch_bounds__(BLOCK) void k_pack_next(const int *__restrict__ lptr, int L, int *__restrict__ nxt, int *__restrict__ w)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l > L) return;
+    if (l == L) { nxt[l] = L; w[l] = 0; return; }
+    const int deg = lptr[l + 1] - lptr[l];
+    if (deg > WTILE) { nxt[l] = l + 1; w[l] = (deg + WTILE - 1) / WTILE; return; }
+    int e = l, nf = 0, nl = 0;
+    while (e < L && nl < TILE_LMKS) {
+        const int d = lptr[e + 1] - lptr[e];
+        if (d > WTILE || nf + d > WTILE) break;
+        nf += d; ++nl; ++e;
+    }
+    nxt[l] = e; w[l] = 1;
+}
+
+// one doubling step: 2^(k+1) hops = 2^k hops twice
+__global__ __launch_bounds__(BLOCK) void k_pack_double(const int *__restrict__ j0, const int *__restrict__ w0, int *__restrict__ j1,
+                                                       int *__restrict__ w1, int n)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l >= n) return;
+    const int m = j0[l];
+    j1[l] = j0[m];
+    w1[l] = w0[l] + w0[m];
+}
+
+// pos[l] = index of the tile that starts at l for the landmarks on the chain from 0 (others stay -1); levels from the top down
+__global__ __launch_bounds__(BLOCK) void k_pack_mark(const int *__restrict__ jk, const int *__restrict__ wk, int *__restrict__ pos, int n)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l >= n) return;
+    const int q = pos[l];
+    if (q < 0) return;
+    const int m = jk[l];
+    if (m != l) pos[m] = q + wk[l];              // (several writers of one entry write the same value)
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pack_emit(const int *__restrict__ lptr, int L, const int *__restrict__ nxt, const int *__restrict__ pos,
+                                                     int4 *__restrict__ tiles, int *__restrict__ lrow0, int *__restrict__ lrow1,
+                                                     int *__restrict__ big_list, int *__restrict__ big_count)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l >= L) return;
+    const int t = pos[l];
+    if (t < 0) return;                                  // inside somebody else's tile
+    const int deg = lptr[l + 1] - lptr[l];
+    if (deg > WTILE) {
+        for (int o = 0, c = 0; o < deg; o += WTILE, ++c) tiles[t + c] = make_int4(l, 0, min(WTILE, deg - o), 0);
+        lrow0[l] = t * WTILE; lrow1[l] = t * WTILE + deg;      // chunk tiles are full except the last: the slots are contiguous
+        big_list[atomicAdd(big_count, 1)] = l;
+        return;
+    }
+    const int e = nxt[l];
+    tiles[t] = make_int4(l, e - l, lptr[e] - lptr[l], 0);
+    for (int m = l; m < e; ++m) {
+        lrow0[m] = t * WTILE + (lptr[m] - lptr[l]);
+        lrow1[m] = t * WTILE + (lptr[m + 1] - lptr[l]);
+    }
 }
 
 struct BuildArgs {

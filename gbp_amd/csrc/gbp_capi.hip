@@ -1,9 +1,9 @@
 // gbp_capi.hip -- host side of libgbp_hip.so: graph lay-out, launches and the C ABI of include/gbp_ba.h.
 //
 // No CPU compute path lives here: every sweep, belief update and diagnostic is a HIP kernel, and so is the graph build
-// (gbp_build.hpp: ordering, slot assignment, initial linearisation points, prior maxima).  Host code only (a) walks the L
-// landmark degrees once to pack tiles, (b) packs/unpacks symmetric matrices for the views, (c) owns handles, streams and
-// the optional RCCL communicator.
+// (gbp_build.hpp: ordering, tile packing, slot assignment, initial linearisation points, prior maxima).  Host code only
+// (a) sizes the allocations from the tile count the device reports, (b) packs/unpacks symmetric matrices for the views,
+// (c) owns handles, streams and the optional RCCL communicator.
 #include "../../include/gbp_ba.h"
 #include "gbp_kernels.hpp"
 #include "gbp_fused.hpp"
@@ -14,10 +14,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -387,18 +389,19 @@ static int stage_input(gbp_ba *h, const T *src, size_t n, bool on_device, std::v
 {
     if (on_device || !n) { *out = src; return GBP_OK; }
     void *q = nullptr;
-    HIPCHK(hipMalloc(&q, n * sizeof(T)));
+    HIPCHK(hipMallocAsync(&q, n * sizeof(T), h->stream));
     scratch.push_back(q);
     HIPCHK(hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
     *out = static_cast<const T *>(q);
     return GBP_OK;
 }
 
+// buffers only the build needs come from the stream-ordered pool (no device synchronisation per allocation or release)
 template <typename T>
-static int scratch_alloc(std::vector<void *> &scratch, T **out, size_t n)
+static int scratch_alloc(gbp_ba *h, std::vector<void *> &scratch, T **out, size_t n)
 {
     void *q = nullptr;
-    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    HIPCHK(hipMallocAsync(&q, std::max<size_t>(n, 1) * sizeof(T), h->stream));
     scratch.push_back(q);
     *out = static_cast<T *>(q);
     return GBP_OK;
@@ -406,8 +409,23 @@ static int scratch_alloc(std::vector<void *> &scratch, T **out, size_t n)
 
 }  // extern "C++"
 
+// GBP_BUILD_TIMING=1: wall time of the stages of gbp_ba_create on stderr (each mark synchronises the stream: diagnostic only)
+struct BuildClock {
+    bool on; hipStream_t s; std::chrono::steady_clock::time_point t0;
+    BuildClock(hipStream_t st) : on(getenv("GBP_BUILD_TIMING") != nullptr), s(st), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gbp build] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &scratch, int n_cus)
 {
+    BuildClock clk(h->stream);
     const int C = d->n_cams, L = d->n_lmks, F = d->n_factors;
     Params &p = h->p;
     const bool dev_in = (d->flags & GBP_FLAG_DEVICE_INPUT) != 0;
@@ -419,9 +437,10 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     CHK(stage_input(h, d->cam_means, (size_t)C * 6, dev_in, scratch, &cam_means));
     CHK(stage_input(h, d->lmk_means, (size_t)L * 3, dev_in, scratch, &lmk_means));
 
+    clk.mark("stage inputs");
     // 1. ids in range?  already camera-major?
     int *d_flags = nullptr;
-    CHK(scratch_alloc(scratch, &d_flags, 2));
+    CHK(scratch_alloc(h, scratch, &d_flags, 2));
     HIPCHK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), h->stream));
     if (F) hipLaunchKernelGGL(k_check_ids, dim3(grid_for(Fz)), dim3(BLOCK), 0, h->stream, cam_idx, lmk_idx, F, C, L, d_flags);
     HIPCHK(hipGetLastError());
@@ -430,22 +449,23 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     HIPCHK(hipStreamSynchronize(h->stream));
     if (flags[0]) return fail(GBP_EINVAL, "an observation references a camera outside [0,%d) or a landmark outside [0,%d)", C, L);
 
+    clk.mark("check ids");
     // 2. reference order: camera-major, stable in file order (gbp_ba.py:128-130)
     int *iota = nullptr, *ref_file = nullptr, *lm_key = nullptr, *lm2ref = nullptr, *lptr = nullptr, *cptr = nullptr, *cadj = nullptr, *cpos = nullptr;
     CHK(dev_alloc(h, &h->d_ref_cam, std::max<size_t>(Fz, 1), false)); CHK(dev_alloc(h, &h->d_ref_lmk, std::max<size_t>(Fz, 1), false));
-    CHK(scratch_alloc(scratch, &iota, Fz)); CHK(scratch_alloc(scratch, &lm_key, Fz)); CHK(scratch_alloc(scratch, &lm2ref, Fz));
-    CHK(scratch_alloc(scratch, &lptr, (size_t)L + 1));
+    CHK(scratch_alloc(h, scratch, &iota, Fz)); CHK(scratch_alloc(h, scratch, &lm_key, Fz)); CHK(scratch_alloc(h, scratch, &lm2ref, Fz));
+    CHK(scratch_alloc(h, scratch, &lptr, (size_t)L + 1));
     CHK(dev_alloc(h, &cptr, (size_t)C + 1)); CHK(dev_alloc(h, &cadj, std::max<size_t>(Fz, 1)));
     int bits_c = 1, bits_l = 1;
     while ((1 << bits_c) < C) ++bits_c;
     while ((1 << bits_l) < L) ++bits_l;
     void *sort_tmp = nullptr;
     const size_t sort_bytes = F ? std::max(sort_pairs_tmp_bytes(Fz, bits_c), sort_pairs_tmp_bytes(Fz, bits_l)) : 0;
-    if (sort_bytes) { HIPCHK(hipMalloc(&sort_tmp, sort_bytes)); scratch.push_back(sort_tmp); }
+    if (sort_bytes) { HIPCHK(hipMallocAsync(&sort_tmp, sort_bytes, h->stream)); scratch.push_back(sort_tmp); }
     if (F) hipLaunchKernelGGL(k_iota, dim3(grid_for(Fz)), dim3(BLOCK), 0, h->stream, iota, F);
     const bool sorted = !flags[1];
     if (F && !sorted) {
-        CHK(scratch_alloc(scratch, &ref_file, Fz));
+        CHK(scratch_alloc(h, scratch, &ref_file, Fz));
         HIPCHK((hipError_t)sort_pairs(sort_tmp, sort_bytes, cam_idx, h->d_ref_cam, iota, ref_file, Fz, bits_c, h->stream));
         hipLaunchKernelGGL(k_gather_int, dim3(grid_for(Fz)), dim3(BLOCK), 0, h->stream, lmk_idx, ref_file, h->d_ref_lmk, F);
     } else if (F) {
@@ -458,58 +478,62 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     hipLaunchKernelGGL(k_lower_bounds, dim3(grid_for((size_t)L + 1)), dim3(BLOCK), 0, h->stream, lm_key, F, lptr, L);
     HIPCHK(hipGetLastError());
 
+    clk.mark("orders (allocs + 2 sorts)");
     // 4. tiles: up to 64 slots / TILE_LMKS whole landmarks each; over-sized landmarks become chunk tiles (nl = 0).
-    //    A next-fit walk over the L degrees: sequential, but L-sized -- done here on the downloaded offsets.
-    std::vector<int32_t> h_lptr;
-    CHK(download(h, h_lptr, lptr, (size_t)L + 1));
-    std::vector<int4> tiles;
-    std::vector<int32_t> lrow0((size_t)std::max(L, 1), 0), lrow1((size_t)std::max(L, 1), 0);
-    {
-        int cur_l0 = 0, cur_nf = 0, cur_nl = 0;
-        auto flush = [&]() {
-            if (cur_nl > 0) tiles.push_back(make_int4(cur_l0, cur_nl, cur_nf, 0));
-            cur_nf = 0; cur_nl = 0;
-        };
-        for (int l = 0; l < L; ++l) {
-            const int deg = h_lptr[l + 1] - h_lptr[l];
-            if (deg > WTILE) {
-                flush();
-                lrow0[l] = (int32_t)(tiles.size() * WTILE);
-                for (int o = 0; o < deg; o += WTILE) tiles.push_back(make_int4(l, 0, std::min(WTILE, deg - o), 0));
-                lrow1[l] = lrow0[l] + deg;          // chunk tiles are full except the last: the slots are contiguous
-                h->big_lmks.push_back(l);
-                continue;
-            }
-            if (cur_nl > 0 && (cur_nf + deg > WTILE || cur_nl == TILE_LMKS)) flush();
-            if (cur_nl == 0) cur_l0 = l;
-            lrow0[l] = (int32_t)(tiles.size() * WTILE) + cur_nf; lrow1[l] = lrow0[l] + deg;
-            cur_nf += deg; cur_nl += 1;
-        }
-        flush();
-    }
-    const int T = (int)tiles.size();
+    //    Next-fit packing as list ranking on the device (gbp_build.hpp); only the tile count and the (few) over-sized landmarks
+    //    come back.
+    const int LP = L + 1;
+    int levels = 1;
+    while ((1 << levels) < LP) ++levels;
+    int *jump = nullptr, *wsum = nullptr, *pos = nullptr, *d_lrow0 = nullptr, *d_lrow1 = nullptr, *d_big_list = nullptr, *d_cnt = nullptr;
+    CHK(scratch_alloc(h, scratch, &jump, (size_t)levels * LP)); CHK(scratch_alloc(h, scratch, &wsum, (size_t)levels * LP));
+    CHK(scratch_alloc(h, scratch, &pos, (size_t)LP));
+    CHK(scratch_alloc(h, scratch, &d_lrow0, (size_t)L)); CHK(scratch_alloc(h, scratch, &d_lrow1, (size_t)L));
+    CHK(scratch_alloc(h, scratch, &d_big_list, (size_t)L)); CHK(scratch_alloc(h, scratch, &d_cnt, 1));
+    HIPCHK(hipMemsetAsync(pos, 0xff, sizeof(int) * (size_t)LP, h->stream));
+    HIPCHK(hipMemsetAsync(pos, 0, sizeof(int), h->stream));                       // the first tile starts at landmark 0
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_pack_next, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, lptr, L, jump, wsum);
+    for (int k = 0; k + 1 < levels; ++k)
+        hipLaunchKernelGGL(k_pack_double, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, jump + (size_t)k * LP, wsum + (size_t)k * LP,
+                           jump + (size_t)(k + 1) * LP, wsum + (size_t)(k + 1) * LP, LP);
+    for (int k = levels - 1; k >= 0; --k)
+        hipLaunchKernelGGL(k_pack_mark, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, jump + (size_t)k * LP, wsum + (size_t)k * LP, pos, LP);
+    HIPCHK(hipGetLastError());
+    int T = 0;
+    HIPCHK(hipMemcpyAsync(&T, pos + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (L == 0) T = 0;
+    if (T < 0 || (int64_t)T * WTILE > INT32_MAX) return fail(GBP_EINVAL, "the graph needs %d tiles: slot indices would not fit 32 bits", T);
     const size_t S = std::max<size_t>((size_t)T * WTILE, 1);
     p.T = T;
+    int4 *d_tiles = nullptr;
+    CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1)));
+    if (L) hipLaunchKernelGGL(k_pack_emit, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, jump, pos, d_tiles, d_lrow0, d_lrow1,
+                              d_big_list, d_cnt);
+    HIPCHK(hipGetLastError());
+    int n_big = 0;
+    HIPCHK(hipMemcpyAsync(&n_big, d_cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_big) {
+        CHK(download(h, h->big_lmks, d_big_list, (size_t)n_big));
+        std::sort(h->big_lmks.begin(), h->big_lmks.end());                        // (the kernel appends them in any order)
+    }
 
+    clk.mark("tile packing");
     // 5. per-slot data
-    unsigned *d_meta = nullptr; int4 *d_tiles = nullptr; int *d_lrow0 = nullptr, *d_lrow1 = nullptr;
+    unsigned *d_meta = nullptr;
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
     if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
-    CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1), false));
-    CHK(scratch_alloc(scratch, &d_lrow0, (size_t)L)); CHK(scratch_alloc(scratch, &d_lrow1, (size_t)L));
     CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
     CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
-    if (T) HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)T * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-    if (L) {
-        HIPCHK(hipMemcpyAsync(d_lrow0, lrow0.data(), (size_t)L * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d_lrow1, lrow1.data(), (size_t)L * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    }
     p.meta = d_meta; p.tiles = d_tiles; p.cptr = cptr; p.cadj = cadj; p.cpos = cpos;
     if (T) {
         BuildArgs a{d_tiles, d_lrow0, lptr, lm2ref, h->d_ref_cam, ref_file, cam_means, lmk_means, meas, d_meta, cadj, cpos};
         hipLaunchKernelGGL(k_build_tiles, dim3((T + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, h->stream, p, a);
     }
+    clk.mark("allocs + k_build_tiles");
     // 6. variables
     if (C + L) hipLaunchKernelGGL(k_init_vars, dim3(grid_for((size_t)C + L)), dim3(BLOCK), 0, h->stream, p, cam_means, lmk_means, d_lrow0, d_lrow1);
     HIPCHK(hipGetLastError());
@@ -520,6 +544,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     CHK(dev_alloc(h, &h->d_count, 2));
     CHK(dev_alloc(h, &h->d_varmax, (size_t)std::max(C + L, 1), false));
 
+    clk.mark("vars + small allocs");
     if (getenv("GBP_DEBUG_LAYOUT")) {
         int bad = 0;
         CHK(gbp_ba_check_layout(h, &bad));
@@ -532,6 +557,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         if (h->fused.enabled) h->dominant = "k_sweep_fused";
     }
     HIPCHK(hipStreamSynchronize(h->stream));                // the staged inputs are released by the caller
+    clk.mark("fused plan");
     return GBP_OK;
 }
 
@@ -544,10 +570,23 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     if (d->device < 0 || d->device >= ndev) return fail(GBP_EINVAL, "device %d out of range (%d visible)", d->device, ndev);
     h->device = d->device;
     HIPCHK(hipSetDevice(h->device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, h->device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(GBP_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", h->device, prop.gcnArchName);
+    // hipGetDeviceProperties costs ~1 ms: asked once per device and process
+    static std::mutex prop_mutex;
+    static std::vector<std::pair<int, std::string>> prop_cache;       // [device] = {CU count, arch}
+    int n_cus = 0;
+    std::string arch;
+    {
+        std::lock_guard<std::mutex> lock(prop_mutex);
+        if ((int)prop_cache.size() < ndev) prop_cache.resize(ndev, {0, std::string()});
+        if (prop_cache[h->device].first == 0) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, h->device));
+            prop_cache[h->device] = {prop.multiProcessorCount, std::string(prop.gcnArchName)};
+        }
+        n_cus = prop_cache[h->device].first; arch = prop_cache[h->device].second;
+    }
+    if (strncmp(arch.c_str(), "gfx950", 6) != 0)
+        return fail(GBP_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", h->device, arch.c_str());
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     h->flags = d->flags;
@@ -564,9 +603,9 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     if (C >= (1 << (32 - META_LMK_BITS))) return fail(GBP_EINVAL, "more than %d cameras are not supported", (1 << (32 - META_LMK_BITS)) - 1);
 
     std::vector<void *> scratch;                             // device buffers only the build needs
-    const int rc = build_graph(h, d, scratch, prop.multiProcessorCount);
+    const int rc = build_graph(h, d, scratch, n_cus);
+    for (void *q : scratch) (void)hipFreeAsync(q, h->stream);
     (void)hipStreamSynchronize(h->stream);
-    for (void *q : scratch) (void)hipFree(q);
     return rc;
 }
 
