@@ -313,6 +313,8 @@ Rccl g_rccl;
 
 int rccl_load(const char *path)
 {
+    static std::mutex load_mutex;                            // ranks as threads of one process may arrive together
+    std::lock_guard<std::mutex> lock(load_mutex);
     if (g_rccl.lib) return GBP_OK;
     void *lib = nullptr;
     if (path && *path) lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);

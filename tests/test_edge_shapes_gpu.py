@@ -200,3 +200,42 @@ def test_damping_in_the_relinearising_sweep(oracle_mod, num_undamped):
     for a, b in zip(e.messages(), o.messages()):
         assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
     assert np.array_equal(o.relin_state()['eta_damping'], e.relin_state()['eta_damping'])
+
+
+def test_degenerate_graphs(oracle_mod):
+    """Shapes the device-side build must survive: no factors at all, landmarks nobody observes (in front, in the middle, at the
+    end), a single factor, a camera without factors."""
+    from gbp_amd.engine import BAEngine
+    base = make_synthetic(n_cams=6, n_lmks=30, obs_per_lmk=3, seed=81)
+    # no factors
+    e = BAEngine(base.K, base.cam_means, base.lmk_means, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert e.info()['n_tiles'] == 2 and e.check_layout() == 0           # 30 landmarks, 24 per tile, no slot used
+    e.iterate(2)
+    e.close()
+    # unobserved landmarks: landmark ids stretched so that 0, 7, 8 and the last two have no factor
+    remap = np.array([1, 2, 3, 4, 5, 6] + list(range(9, 33)))
+    lm = np.concatenate([base.lmk_means[:1], base.lmk_means[:6], base.lmk_means[:2], base.lmk_means[6:], base.lmk_means[:2]])
+    prob = BAProblem(K=base.K, cam_means=base.cam_means, lmk_means=lm, meas=base.meas, cam_idx=base.cam_idx,
+                     lmk_idx=remap[base.lmk_idx].astype(np.int32))
+    # a camera without factors: drop camera 5's observations
+    keep = prob.cam_idx != 5
+    prob = BAProblem(K=prob.K, cam_means=prob.cam_means, lmk_means=prob.lmk_means, meas=prob.meas[keep], cam_idx=prob.cam_idx[keep],
+                     lmk_idx=prob.lmk_idx[keep])
+    for fused in (True, False):
+        o = oracle_mod.OracleBA.from_problem(prob)
+        e = BAEngine.from_problem(prob, fused=fused)
+        assert e.check_layout() == 0
+        for g in (o, e):
+            g.generate_priors_var(50.0)
+        # variables without factors get a zero prior (max over no factors = 0, gbp_ba.py:27): their belief is singular in the
+        # reference too, so the sweep is compared on the variables that have factors
+        po, pe = o.priors(), e.priors()
+        for a, b in zip(pe, po):
+            assert np.allclose(a, b, rtol=1e-10, atol=0.0)
+        assert not pe[1][5].any() and not pe[3][0].any() and not pe[3][-1].any()      # camera 5, first and last landmark: no factor
+        e.close()
+    # a single factor
+    one = BAProblem(K=base.K, cam_means=base.cam_means[:1], lmk_means=base.lmk_means[:1], meas=base.meas[:1],
+                    cam_idx=np.zeros(1, np.int32), lmk_idx=np.zeros(1, np.int32))
+    gap, o, e = run_pair(oracle_mod, one, n_sweeps=6)
+    assert gap < BELIEF_TOL and e.info()['n_tiles'] == 1
