@@ -10,7 +10,7 @@ fixed, so scaling is "strong".  Started without torchrun, `--gpus N` spawns its 
 torch.distributed.run on 127.0.0.1); started under torchrun it uses the ranks it is given.  Rank 0 prints ONE JSON line.
 
 Timing protocol.  Every batch starts from the same state -- the graph right after generate_priors_var +
-update_all_beliefs, restored from a checkpoint -- runs W untimed sweeps and then EXACTLY K timed sweeps bracketed by a
+update_all_beliefs, restored from a device-resident checkpoint -- runs W untimed sweeps and then EXACTLY K timed sweeps bracketed by a
 barrier + device synchronisation on both sides (max over ranks).  Batches are repeated until >= 0.5 s have been timed;
 `value` = K / median batch time, the minimum is reported beside it.  HIP events bracket every launch of the dominant
 kernel in one extra, untimed replay of the same batch, and the device counts the factors that relinearise in each sweep:
@@ -228,12 +228,13 @@ def main():
     graph.generate_priors_var(50.0)
     graph.update_all_beliefs()
     graph.sync()
-    state0 = None if dry else graph.save_state()
+    if not dry:
+        graph.snapshot_state()                                 # device-resident: restoring it leaves no idle gap before the sweeps
 
     def batch(timing=False):
         """Restore the initial state, W untimed sweeps, then K sweeps between two fences.  Returns wall seconds (max over ranks)."""
-        if state0 is not None:
-            graph.load_state(state0)
+        if not dry:
+            graph.restore_snapshot()
         graph.iterate(args.warmup)
         graph.sync()
         if timing:

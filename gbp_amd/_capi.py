@@ -101,6 +101,8 @@ SIGNATURES = {
     'gbp_ba_state_size': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_uint64)]),
     'gbp_ba_save_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
     'gbp_ba_load_state': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_uint64]),
+    'gbp_ba_snapshot_state': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_restore_snapshot': (ct.c_int, [ct.c_void_p]),
     'gbp_lin_create': (ct.c_int, [ct.POINTER(ct.c_void_p), ct.c_void_p]),
     'gbp_lin_destroy': (None, [ct.c_void_p]),
     'gbp_lin_sync': (ct.c_int, [ct.c_void_p]),

@@ -74,6 +74,7 @@ struct gbp_ba {
     std::vector<int32_t> big_lmks;               // landmarks larger than a tile
     int *d_big = nullptr;                        // the same on the device (general sweep)
     bool hash_ok = false; uint64_t hash = 0;     // digest of the layout (state blobs)
+    std::vector<void *> snap; bool snap_has_beliefs = false;   // device-resident checkpoint (gbp_ba_snapshot_state)
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -369,6 +370,7 @@ void gbp_ba_destroy(gbp_ba_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *ptr : h->allocs) (void)hipFree(ptr);
     if (h->d_tmp) (void)hipFree(h->d_tmp);
+    for (void *q : h->snap) if (q) (void)hipFree(q);
     if (h->d_send) (void)hipFree(h->d_send);
     if (h->d_recv) (void)hipFree(h->d_recv);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -1318,6 +1320,37 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
         out += q.bytes;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    return GBP_OK;
+}
+
+// Device-resident checkpoint: the same parts copied to a second set of buffers on the GPU (0.2 GB at 1M factors) and back.
+// Restoring costs a device-to-device copy (~0.15 ms at 1M factors) instead of a PCIe upload, and the GPU never idles in between.
+int gbp_ba_snapshot_state(gbp_ba_t *h)
+{
+    ENTER(h);
+    std::vector<StatePart> parts = state_parts(h);
+    if (h->snap.empty()) {
+        for (const StatePart &q : parts) {
+            void *d = nullptr;
+            if (q.bytes) HIPCHK(hipMalloc(&d, q.bytes));
+            h->snap.push_back(d);
+        }
+    }
+    for (size_t i = 0; i < parts.size(); ++i)
+        if (parts[i].bytes) HIPCHK(hipMemcpyAsync(h->snap[i], parts[i].dev, parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->snap_has_beliefs = h->has_beliefs;
+    return GBP_OK;
+}
+
+int gbp_ba_restore_snapshot(gbp_ba_t *h)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    if (h->snap.empty()) return fail(GBP_ESTATE, "no snapshot taken (gbp_ba_snapshot_state)");
+    std::vector<StatePart> parts = state_parts(h);
+    for (size_t i = 0; i < parts.size(); ++i)
+        if (parts[i].bytes) HIPCHK(hipMemcpyAsync(parts[i].dev, h->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->has_beliefs = h->snap_has_beliefs;
     return GBP_OK;
 }
 

@@ -307,6 +307,13 @@ class BAEngine:
         buf = np.ascontiguousarray(blob, dtype=np.uint8)
         check(self._lib.gbp_ba_load_state(self._h, buf.ctypes.data_as(ct.c_void_p), ct.c_uint64(buf.size)))
 
+    def snapshot_state(self):
+        """Checkpoint kept on the device (one slot); restore_snapshot() brings it back with a device-to-device copy."""
+        check(self._lib.gbp_ba_snapshot_state(self._h))
+
+    def restore_snapshot(self):
+        check(self._lib.gbp_ba_restore_snapshot(self._h))
+
     def save(self, path):
         np.save(path, self.save_state(), allow_pickle=False)
 

@@ -217,6 +217,12 @@ class ShardedBA:
     def load_state(self, blob):
         self.engine.load_state(blob)
 
+    def snapshot_state(self):
+        self.engine.snapshot_state()
+
+    def restore_snapshot(self):
+        self.engine.restore_snapshot()
+
     def kernel_times(self):
         return self.engine.kernel_times()
 

@@ -174,6 +174,9 @@ int gbp_bal_read(const char *path, int32_t n_cams, int32_t n_lmks, int32_t n_obs
 int gbp_ba_state_size(gbp_ba_t *h, uint64_t *bytes);
 int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes);
 int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes);
+/* the same checkpoint kept on the device (one slot per handle): restore is a device-to-device copy in stream order */
+int gbp_ba_snapshot_state(gbp_ba_t *h);
+int gbp_ba_restore_snapshot(gbp_ba_t *h);
 
 /* instrumentation for bench.py: HIP-event time of the dominant (factor) kernel on the handle's stream; enable = n > 1
  * brackets only every n-th launch (two event records per sweep are not free: ~6 us of a 125 us sweep) */

@@ -239,3 +239,24 @@ def test_degenerate_graphs(oracle_mod):
                     cam_idx=np.zeros(1, np.int32), lmk_idx=np.zeros(1, np.int32))
     gap, o, e = run_pair(oracle_mod, one, n_sweeps=6)
     assert gap < BELIEF_TOL and e.info()['n_tiles'] == 1
+
+
+def test_device_resident_checkpoint():
+    """gbp_ba_snapshot_state / gbp_ba_restore_snapshot: the continuation from the restored state is bit-identical."""
+    from gbp_amd import _capi
+    from gbp_amd.engine import BAEngine
+    p = make_synthetic(n_cams=12, n_lmks=400, obs_per_lmk=5, seed=91)
+    e = BAEngine.from_problem(p)
+    with pytest.raises(_capi.GbpError):
+        e.restore_snapshot()
+    e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(7)
+    e.snapshot_state()
+    e.iterate(9)
+    a = e.beliefs(); st_a = e.relin_state()['iters_since_relin']
+    e.restore_snapshot()
+    e.iterate(9)
+    b = e.beliefs()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and np.array_equal(st_a, e.relin_state()['iters_since_relin'])
+    blob = e.save_state()                       # the host blob and the device slot are independent
+    e.restore_snapshot(); e.iterate(2); e.load_state(blob)
+    assert all(np.array_equal(x, y) for x, y in zip(a, e.beliefs()))
