@@ -113,6 +113,7 @@ SIGNATURES = {
     'gbp_lin_get_means': (ct.c_int, [ct.c_void_p, _dp]),
     'gbp_lin_get_messages': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
     'gbp_ba_fused_max_cams': (ct.c_int, []),
+    'gbp_ba_grouped_max_cams': (ct.c_int, []),
     'gbp_ba_phase_profile': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     'gbp_ba_check_layout': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32)]),
     'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),

@@ -1485,6 +1485,11 @@ int gbp_ba_fused_max_cams(void)
     return fused_max_cams();
 }
 
+int gbp_ba_grouped_max_cams(void)
+{
+    return fused_max_cams() + (MAX_CAM_GROUPS - 1) * pass_max_cams();
+}
+
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks)
 {
     if (!h) return fail(GBP_EINVAL, "null handle");

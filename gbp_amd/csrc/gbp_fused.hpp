@@ -34,7 +34,7 @@
 //
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
-// (C > 516) the cameras are split into up to three groups: the sweep adds up the first, k_cam_pass the others; beyond that the
+// (C > 516) the cameras are split into two groups (516 + up to 758): the sweep adds up the first, k_cam_pass the others; beyond that the
 // plan stays disabled and the general sweep runs.
 #pragma once
 #include "gbp_kernels.hpp"
@@ -404,7 +404,8 @@ constexpr int PASS_WAVES = 16;                      // k_cam_pass keeps little s
 
 struct FusedPlan {
     bool enabled = false;
-    int n_groups = 0, group_cams = 0;               // camera groups of at most group_cams cameras (1 group: everything in one launch)
+    int n_groups = 0, group_cams = 0, pass_cams = 0; // the sweep adds up the first group_cams cameras, every k_cam_pass launch pass_cams more
+    size_t pass_shmem = 0;
     int n_blocks = 0, n_big = 0;
     size_t shmem = 0;
     FusedArgs args{};
@@ -440,6 +441,9 @@ inline size_t fused_shmem(int C)
     return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES) + 2);
 }
 
+// most cameras one k_cam_pass launch adds up: its table and two control words are all it keeps in the LDS
+inline int pass_max_cams() { return (LDS_BYTES - 16) / (27 * (int)sizeof(double)); }
+
 // most cameras whose table + the per-wave scratch fit the LDS (the plan falls back to the general sweep above it)
 inline int fused_max_cams()
 {
@@ -452,12 +456,15 @@ inline int fused_max_cams()
 inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
 {
     if (p.F == 0 || p.C == 0 || p.T == 0) return 0;
-    const int cmax = fused_max_cams();
-    pl.n_groups = (p.C + cmax - 1) / cmax;
-    if (pl.n_groups > MAX_CAM_GROUPS) return 0;                                        // general sweep instead
-    pl.group_cams = (p.C + pl.n_groups - 1) / pl.n_groups;
+    // the sweep's own table shares the LDS with the waves' scratch (516 cameras); k_cam_pass has the LDS to itself (758)
+    const int cmax = fused_max_cams(), pmax = pass_max_cams();
+    if (p.C > cmax + (MAX_CAM_GROUPS - 1) * pmax) return 0;                            // general sweep instead
+    pl.group_cams = std::min(p.C, cmax);
+    pl.n_groups = 1 + (p.C - pl.group_cams + pmax - 1) / pmax;
+    pl.pass_cams = pl.n_groups > 1 ? (p.C - pl.group_cams + pl.n_groups - 2) / (pl.n_groups - 1) : 0;
     const int acc_doubles = pl.group_cams * 27;
     const size_t shmem = fused_shmem(pl.group_cams);
+    pl.pass_shmem = sizeof(double) * (size_t)(((pl.pass_cams * 27 + 1) & ~1) + 2);
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     std::vector<int32_t> blk((size_t)pl.n_blocks + 1);
     for (int b = 0; b <= pl.n_blocks; ++b) blk[b] = (int32_t)((int64_t)b * p.T / pl.n_blocks);
@@ -478,7 +485,8 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
                             (int)shmem) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
-    GBP_SET_SHMEM((k_cam_pass<PASS_WAVES>))
+    if (pl.n_groups > 1 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_pass<PASS_WAVES>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pass_shmem) != hipSuccess) return -1;
 #undef GBP_SET_SHMEM
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
@@ -502,10 +510,10 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     if (e1) (void)hipEventRecord(e1, stream);
     for (int g = 1; g < pl.n_groups; ++g) {                 // the messages to the cameras of the further groups (C > 516)
         FusedArgs ag = pl.args;
-        ag.cam_base = g * pl.group_cams;
-        ag.cam_count = std::min(p.C - ag.cam_base, pl.group_cams);
+        ag.cam_base = pl.group_cams + (g - 1) * pl.pass_cams;
+        ag.cam_count = std::min(p.C - ag.cam_base, pl.pass_cams);
         ag.acc_doubles = ag.cam_count * 27;
-        hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.shmem, stream, p, ag, p.tiles, pl.d_blk);
+        hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.pass_shmem, stream, p, ag, p.tiles, pl.d_blk);
     }
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
     const size_t red_shmem = sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27);

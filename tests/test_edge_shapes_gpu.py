@@ -30,7 +30,9 @@ def test_camera_count_at_the_lds_boundary(oracle_mod):
     cmax = _capi.load().gbp_ba_fused_max_cams()
     assert 256 <= cmax <= 758                       # 160 KB / 216 B per camera, minus the per-wave scratch
     # one table / two camera groups (k_cam_pass) / three groups would be needed: the staged general sweep
-    for C, groups in ((cmax, 1), (cmax + 1, 2), (2 * cmax, 2), (2 * cmax + 1, 0)):
+    gmax = _capi.load().gbp_ba_grouped_max_cams()
+    assert gmax == cmax + 758
+    for C, groups in ((cmax, 1), (cmax + 1, 2), (gmax, 2), (gmax + 1, 0)):
         prob = make_synthetic(n_cams=C, n_lmks=900, obs_per_lmk=6, seed=21)
         gap, o, e = run_pair(oracle_mod, prob, n_sweeps=10)
         assert e.info()['cam_groups'] == groups, (C, e.info())
