@@ -159,3 +159,34 @@ def test_sharded_engine_synthetic_two_ranks(oracle_mod):
     for r, (ce, cl), ((a, b), le, ll) in shared_ranks:
         assert rel_err_rows(ce, rce) < 1e-6 and rel_err_rows(cl, rcl) < 1e-6
         assert rel_err_rows(le, rle[a:b]) < 1e-6 and rel_err_rows(ll, rll[a:b]) < 1e-6
+
+
+def test_sharded_engine_with_camera_groups_and_oversized_landmarks(oracle_mod):
+    """700 cameras (two camera groups: fused sweep + k_cam_pass) and landmarks seen by more than 64 cameras (chunk tiles whose
+    beliefs run on the side stream beside the exchange) through the in-library loop at world size 2."""
+    from gbp_amd.engine import BAEngine
+    from gbp_amd.synthetic import BAProblem
+    big = make_synthetic(n_cams=700, n_lmks=3, obs_per_lmk=90, seed=8)
+    q = make_synthetic(n_cams=700, n_lmks=1200, obs_per_lmk=6, seed=9)
+    # the over-sized landmarks go to both ends so that each rank owns some
+    lm = np.concatenate([big.lmk_means[:2], q.lmk_means, big.lmk_means[2:]])
+    lidx = np.concatenate([big.lmk_idx[big.lmk_idx < 2], q.lmk_idx + 2, big.lmk_idx[big.lmk_idx == 2] - 2 + 2 + q.n_lmks])
+    cidx = np.concatenate([big.cam_idx[big.lmk_idx < 2], q.cam_idx, big.cam_idx[big.lmk_idx == 2]])
+    meas = np.concatenate([big.meas[big.lmk_idx < 2], q.meas, big.meas[big.lmk_idx == 2]])
+    p = BAProblem(K=q.K, cam_means=q.cam_means, lmk_means=lm, meas=meas, cam_idx=cidx.astype(np.int32), lmk_idx=lidx.astype(np.int32))
+    ref = BAEngine.from_problem(p)
+    assert ref.info()['cam_groups'] == 2
+    ref.generate_priors_var(50.0); ref.update_all_beliefs()
+    ares, energies = oracle_mod.replay_ba(ref, 10, diagnostics=True)
+    rce, rcl, rle, rll = ref.beliefs()
+    ranks = run_world(p, 2, True, 10, oracle_mod, True)
+    lo = 0
+    for r in ranks:
+        assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])
+        assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
+        a, b = r['rng']
+        assert a == lo
+        lo = b
+        assert rel_err_rows(r['le'], rle[a:b]) < 1e-6 and rel_err_rows(r['ll'], rll[a:b]) < 1e-6
+        assert np.allclose(r['ares'], ares, rtol=1e-7)
+    assert lo == p.n_lmks
