@@ -74,7 +74,8 @@ struct gbp_ba {
     std::vector<int32_t> big_lmks;               // landmarks larger than a tile
     int *d_big = nullptr;                        // the same on the device (general sweep)
     bool hash_ok = false; uint64_t hash = 0;     // digest of the layout (state blobs)
-    std::vector<void *> snap; bool snap_has_beliefs = false;   // device-resident checkpoint (gbp_ba_snapshot_state)
+    void *arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
+    std::vector<void *> snap; bool snap_has_beliefs = false; uint32_t snap_parity = 0;   // device-resident checkpoint (gbp_ba_snapshot_state)
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -100,7 +101,9 @@ struct gbp_ba {
     // per-sweep count of relinearising factors: ring of device counters, half of it cleared whenever the sweep index
     // enters it, so the last RELIN_RING/2 sweeps are always readable
     int *d_relin_ring = nullptr;
-    long sweep_count = 0;
+    long sweep_count = 0;                        // sweeps since create (index into the relin ring)
+    uint32_t walk_parity = 0;                    // part of the STATE: odd sweeps walk the tiles backwards, so a restored handle must
+                                                 // resume with the parity it was saved with to continue bit-identically
     int *d_count = nullptr;                      // scratch counter of gbp_ba_count_relinearising / gbp_ba_check_layout
     double *d_varmax = nullptr;                  // C + L: per-variable max of Lambda_f, or the prior scalars on their way in
     // landmark-sharded sweep: the camera exchange (include/gbp_ba.h gbp_ba_set_exchange / gbp_ba_comm_init_rccl)
@@ -119,11 +122,41 @@ static int dev_alloc(gbp_ba *h, T **out, size_t n, bool zero = true)
 {
     void *ptr = nullptr;
     size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    HIPCHK(hipMalloc(&ptr, bytes));
-    h->allocs.push_back(ptr);
+    const size_t off = (h->arena_used + 4095) & ~(size_t)4095;
+    if (h->arena && off + bytes <= h->arena_bytes) {    // what a sweep streams lives in ONE allocation (see arena_reserve)
+        ptr = static_cast<char *>(h->arena) + off;
+        h->arena_used = off + bytes;
+    } else {
+        HIPCHK(hipMalloc(&ptr, bytes));
+        h->allocs.push_back(ptr);
+    }
     if (zero) HIPCHK(hipMemsetAsync(ptr, 0, bytes, h->stream));
     *out = static_cast<T *>(ptr);
     return GBP_OK;
+}
+
+// One allocation for everything a sweep streams (factor streams, landmark records, the workgroup tables, the small per-camera
+// and control buffers).  Not a convenience: at the headline size the working set of a sweep (243 MB) is about the size of the
+// 256 MiB Infinity Cache, and the SAME kernel on the SAME data ran 87 or 95-105 us per sweep depending on where a dozen separate
+// hipMalloc blocks happened to land (one engine in four in the slow mode, tools/placement_probe.py); out of one block the slow
+// mode becomes rare.  It also saves a dozen allocation calls (most of what is left of gbp_ba_create's time).
+static int arena_reserve(gbp_ba *h, size_t bytes)
+{
+    if (h->arena || getenv("GBP_NO_ARENA")) return GBP_OK;
+    HIPCHK(hipMalloc(&h->arena, bytes));
+    h->allocs.push_back(h->arena);
+    h->arena_bytes = bytes;
+    h->arena_used = 0;
+    return GBP_OK;
+}
+
+static void *arena_take(void *ctx, size_t bytes)          // FusedPlan's allocator hook
+{
+    gbp_ba *h = static_cast<gbp_ba *>(ctx);
+    const size_t off = (h->arena_used + 4095) & ~(size_t)4095;
+    if (!h->arena || off + bytes > h->arena_bytes) return nullptr;
+    h->arena_used = off + bytes;
+    return static_cast<char *>(h->arena) + off;
 }
 
 static int ensure_tmp(gbp_ba *h, size_t bytes)
@@ -277,7 +310,14 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
             e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
             h->ev_used += 2;
         }
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big);
+        // Every other sweep walks each workgroup's tile range backwards: what the last sweep touched last is touched first, so
+        // whatever part of the state the Infinity Cache still holds is used before it is evicted (GBP_NO_REVERSE: experiment
+        // switch).  With arena_reserve this removed the slow mode of the 1M-factor graph (12 of 12 fresh processes at
+        // 11.6-12.1k sweeps/s; 7 of 12 at 10.0-10.7k without both).
+        static const bool no_rev = getenv("GBP_NO_REVERSE") != nullptr;
+        const int reverse = no_rev ? 0 : (int)(h->walk_parity & 1u);
+        h->walk_parity ^= 1u;
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse);
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (finished) *finished = finish != 0;
         return GBP_OK;
@@ -527,6 +567,15 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     clk.mark("tile packing");
     // 5. per-slot data
     unsigned *d_meta = nullptr;
+    {
+        const int n_wg = std::max(1, std::min(T, n_cus));
+        const size_t need = S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
+                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * 27 * sizeof(double)
+                          + (size_t)std::max(C, 1) * (CAMREC + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
+                          + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
+                          + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);
+        CHK(arena_reserve(h, need));
+    }
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
     if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
@@ -556,12 +605,16 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     }
     if (!(h->flags & GBP_FLAG_NO_FUSED) && !p.xtra) {
         HIPCHK(hipStreamSynchronize(h->stream));            // tiles[].w (max rank) is written by k_build_tiles
+        h->fused.alloc = arena_take; h->fused.alloc_ctx = h;
         int rc = fused_plan(h->fused, p, h->big_lmks, h->stream, n_cus);
         if (rc < 0) return fail(GBP_EHIP, "building the fused sweep plan failed (%d)", rc);
         if (h->fused.enabled) h->dominant = "k_sweep_fused";
     }
     HIPCHK(hipStreamSynchronize(h->stream));                // the staged inputs are released by the caller
     clk.mark("fused plan");
+    if (getenv("GBP_PRINT_PTRS"))
+        fprintf(stderr, "[gbp ptrs] lin %p msg %p state %p meta %p lrec %p cbel %p tables %p\n", (void *)p.lin, (void *)p.msg, (void *)p.state,
+                (const void *)p.meta, (void *)p.lrec, (void *)p.cbel, (void *)h->fused.args.block_partials);
     return GBP_OK;
 }
 
@@ -594,6 +647,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     h->flags = d->flags;
+
 
     Params &p = h->p;
     p.F = d->n_factors; p.L = d->n_lmks; p.C = C; p.T = 0;
@@ -1255,6 +1309,7 @@ namespace {
 struct StateHeader {
     char magic[8];                 // "GBPSTATE"
     uint32_t version, has_beliefs;
+    uint32_t walk_parity, reserved;
     int32_t F, T, L, C;
     uint64_t graph_hash;           // digest of the factor -> (slot, camera, landmark) maps (k_graph_hash)
     uint64_t payload_bytes;
@@ -1308,7 +1363,8 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
-    hd.version = 3; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.version = 4; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.walk_parity = h->walk_parity; hd.reserved = 0;
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
     CHK(graph_hash(h, &hd.graph_hash));
     hd.payload_bytes = need - sizeof(StateHeader);
@@ -1339,6 +1395,7 @@ int gbp_ba_snapshot_state(gbp_ba_t *h)
     for (size_t i = 0; i < parts.size(); ++i)
         if (parts[i].bytes) HIPCHK(hipMemcpyAsync(h->snap[i], parts[i].dev, parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
     h->snap_has_beliefs = h->has_beliefs;
+    h->snap_parity = h->walk_parity;
     return GBP_OK;
 }
 
@@ -1351,6 +1408,7 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h)
     for (size_t i = 0; i < parts.size(); ++i)
         if (parts[i].bytes) HIPCHK(hipMemcpyAsync(parts[i].dev, h->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
     h->has_beliefs = h->snap_has_beliefs;
+    h->walk_parity = h->snap_parity;
     return GBP_OK;
 }
 
@@ -1363,7 +1421,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
-    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 3) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
+    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 4) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)
@@ -1376,6 +1434,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->has_beliefs = hd.has_beliefs != 0;
+    h->walk_parity = hd.walk_parity & 1u;
     return GBP_OK;
 }
 

@@ -55,6 +55,7 @@ struct FusedArgs {
     double *block_partials;     // [C][n_blocks][27]
     int acc_doubles;            // cameras of the group * 27
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
+    int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase,
                                 // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results)
     unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
         const bool valid = ti < ntl;
-        const int t = tb + (valid ? ti : 0);
+        const int t = tb + (valid ? (a.reverse ? ntl - 1 - ti : ti) : 0);
         int4 td = make_int4(0, 0, 0, 0);
         if (valid) td = tiles[t];
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a,
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
         if (ti >= ntl) break;
-        const int t = tb + ti;
+        const int t = tb + (a.reverse ? ntl - 1 - ti : ti);
         const int4 td = tiles[t];
         const int slot = t * WTILE + lane;
         const unsigned meta = p.meta[slot];
@@ -412,6 +413,8 @@ struct FusedPlan {
     const int *d_blk = nullptr;
     int *d_big = nullptr;
     std::vector<void *> allocs;
+    void *(*alloc)(void *ctx, size_t bytes) = nullptr;   // optional: take device memory from the owner's arena (else hipMalloc)
+    void *alloc_ctx = nullptr;
 };
 
 inline void fused_destroy(FusedPlan &pl)
@@ -424,9 +427,11 @@ inline void fused_destroy(FusedPlan &pl)
 template <typename T>
 inline int fused_upload(FusedPlan &pl, T **dst, const T *src, size_t n, hipStream_t stream)
 {
-    void *q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return -1;
-    pl.allocs.push_back(q);
+    void *q = pl.alloc ? pl.alloc(pl.alloc_ctx, std::max<size_t>(n, 1) * sizeof(T)) : nullptr;
+    if (!q) {
+        if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return -1;
+        pl.allocs.push_back(q);
+    }
     if (src && n) {
         if (hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(stream) != hipSuccess) return -1;
@@ -478,7 +483,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 #ifdef GBP_PHASE_TIMING
     if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
 #endif
-    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), env_dbg ? atoi(env_dbg) : 0, d_phase};
+    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, env_dbg ? atoi(env_dbg) : 0, d_phase};
     pl.d_blk = d_blk;
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
@@ -496,8 +501,9 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 
 // returns 0 or a hipError_t value
 inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int local_relin, double *partial, hipStream_t stream,
-                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false)
+                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false, int reverse = 0)
 {
+    pl.args.reverse = reverse;
     Params p = p0;
     p.robustify = robustify; p.local_relin = local_relin;
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);

@@ -337,19 +337,19 @@ def test_checkpoint_restore_continues_bit_identically(eng_mod, fused, tmp_path):
     schedule); a blob of a different graph is refused."""
     p, e = make(eng_mod, 'fr1desk_vsmall.txt', fused=fused)
     e.set_iters_since_relin(1)
-    e.iterate(6)
+    e.iterate(7)                                 # odd: the tile-walk direction of the next sweep is part of the state
     blob = e.save_state()
-    e.iterate(12)
+    e.iterate(11)
     want_b, want_m, want_s = e.beliefs(), e.messages(), e.relin_state()
     e.load_state(blob)
-    e.iterate(12)
+    e.iterate(11)
     for a, b in zip(e.beliefs(), want_b):
         assert np.array_equal(a, b)
     fresh = eng_mod.BAEngine.from_problem(p, fused=fused)
     path = os.path.join(tmp_path, 'state.npy')
     np.save(path, blob)
     fresh.load(path)
-    fresh.iterate(12)
+    fresh.iterate(11)
     for a, b in zip(fresh.beliefs(), want_b):
         assert np.array_equal(a, b)
     got_m, got_s = fresh.messages(), fresh.relin_state()
