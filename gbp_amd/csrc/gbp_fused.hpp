@@ -47,7 +47,6 @@ namespace gbp {
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int WAT_WAVES = 8;
 constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][24] landmark records, then [64][9] messages
-constexpr int LPRI = 10;                            // prior 9 | {row0,row1}: what the tail of a tile needs per landmark
 constexpr int WAVE_PRIOR_DOUBLES = TILE_LMKS * LPRI;
 static_assert(TILE_LMKS * LREC <= WAVE_LDS_DOUBLES, "landmark records of a tile must fit the wave scratch");
 
@@ -77,44 +76,6 @@ constexpr int NPHASE = 10;
 #define GBP_PH_FLUSH(ptr, row)
 #endif
 
-GBP_DEV void wave_lds_sync()
-{
-    // all LDS traffic of this wave issued so far has completed; nothing may be moved across
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// The landmark beliefs of a tile from the wave's LDS scratch: prior + messages in adj_factors order (gbp.py:182-193), then
-// mu = Lambda^-1 eta.  Nine lanes per landmark add one belief entry each (seven landmarks per pass; the order of the additions
-// per entry is the reference's), the sums go back through the prior slots, and one lane per landmark does the 3x3 solve and
-// writes the record.  (One lane per landmark reading 9 doubles per message was the longest phase of the loop: 27 % of the
-// wave-time with 6 of 64 lanes busy, tools/phase_profile.py.)
-GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, double *wp, int lane, int t, int l0, int nl)
-{
-    for (int base = 0; base < nl; base += 7) {
-        const int g = (lane * 57) >> 9;                     // lane / 9 for lane < 64
-        const int li = base + g, k = lane - g * 9;
-        if (g < 7 && li < nl) {
-            double *pr = wp + li * LPRI;
-            const int2 rows = *reinterpret_cast<const int2 *>(pr + 9);
-            double b = pr[k];
-            for (int r = rows.x - t * WTILE; r < rows.y - t * WTILE; ++r) b += wl[r * 9 + k];
-            pr[k] = b;
-        }
-    }
-    wave_lds_sync();
-    if (lane < nl) {
-        const double *pr = wp + lane * LPRI;
-        double b[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) b[k] = pr[k];
-        double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
-        double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(l0 + lane) * LREC);
-        dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
-        dst[2] = make_double2(b[4], b[5]); dst[3] = make_double2(b[6], b[7]);
-        spd_solve<3>(lam, eta, mu);
-        dst[4] = make_double2(b[8], mu[0]); dst[5] = make_double2(mu[1], mu[2]);
-    }
-}
 
 template <int LOSS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles,

@@ -312,6 +312,47 @@ GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (
     rank2_update<3>(ML, Jl[0], Jl[1], VL, 1.0);
 }
 
+constexpr int LPRI = 10;           // prior 9 | {row0,row1}: what the belief phase of a tile needs per landmark (LDS)
+
+GBP_DEV void wave_lds_sync()
+{
+    // all LDS traffic of this wave issued so far has completed; nothing may be moved across
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// The landmark beliefs of a tile from the wave's LDS scratch: prior + messages in adj_factors order (gbp.py:182-193), then
+// mu = Lambda^-1 eta.  Nine lanes per landmark add one belief entry each (seven landmarks per pass; the order of the additions
+// per entry is the reference's), the sums go back through the prior slots, and one lane per landmark does the 3x3 solve and
+// writes the record.  (One lane per landmark reading 9 doubles per message was the longest phase of the loop: 27 % of the
+// wave-time with 6 of 64 lanes busy, tools/phase_profile.py.)
+GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, double *wp, int lane, int t, int l0, int nl)
+{
+    for (int base = 0; base < nl; base += 7) {
+        const int g = (lane * 57) >> 9;                     // lane / 9 for lane < 64
+        const int li = base + g, k = lane - g * 9;
+        if (g < 7 && li < nl) {
+            double *pr = wp + li * LPRI;
+            const int2 rows = *reinterpret_cast<const int2 *>(pr + 9);
+            double b = pr[k];
+            for (int r = rows.x - t * WTILE; r < rows.y - t * WTILE; ++r) b += wl[r * 9 + k];
+            pr[k] = b;
+        }
+    }
+    wave_lds_sync();
+    if (lane < nl) {
+        const double *pr = wp + lane * LPRI;
+        double b[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = pr[k];
+        double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
+        double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(l0 + lane) * LREC);
+        dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
+        dst[2] = make_double2(b[4], b[5]); dst[3] = make_double2(b[6], b[7]);
+        spd_solve<3>(lam, eta, mu);
+        dst[4] = make_double2(b[8], mu[0]); dst[5] = make_double2(mu[1], mu[2]);
+    }
+}
+
 // ------------------------------------------------------------- general sweep, tile version --
 // One WAVE per tile: the per-factor part of synchronous_iteration (both messages computed from the OLD messages and
 // committed together, Factor.compute_messages gbp.py:334-373), plus what the tile structure gives for free when the
@@ -327,6 +368,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 {
     __shared__ double wls[BLOCK / 64][WTILE * CSTAGE_ROW];  // per wave: [64][9] landmark messages, then [64][20] camera-message rows
     __shared__ int wps[BLOCK / 64][WTILE];
+    __shared__ double wprs[BLOCK / 64][TILE_LMKS * LPRI];   // per wave: prior | rows of the tile's landmarks
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int t = blockIdx.x * (BLOCK / 64) + wave;
     if (t >= p.T) return;                                   // whole wave
@@ -396,24 +438,15 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
             for (int k = 0; k < 6; ++k) srow[CSTAGE_USED + k] = p.xtra[(size_t)slot * XTRA_ROW + k];
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's LDS writes are done (one wave: no barrier needed)
-    if (lane < nl) {                                        // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks
-        double *lr = p.lrec + (size_t)(l0 + lane) * LREC;
-        double b[9];
+    // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks: priors | rows into LDS, then nine lanes per landmark
+    if (lane < nl) {
+        const double *lr = p.lrec + (size_t)(l0 + lane) * LREC;
+        double *dst = wprs[wave] + lane * LPRI;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) b[k] = lr[LR_PRIOR + k];
-        const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
-        for (int r = rows.x - t * WTILE; r < rows.y - t * WTILE; ++r) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) b[k] += wl[r * 9 + k];
-        }
-        double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) lr[LR_BEL + k] = b[k];
-        spd_solve<3>(lam, eta, mu);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) lr[LR_MU + k] = mu[k];
+        for (int k = 0; k < LPRI; ++k) dst[k] = lr[LR_PRIOR + k];
     }
+    wave_lds_sync();                                        // the wave's LDS writes are done (one wave: no barrier needed)
+    tile_landmark_beliefs(p, wl, wprs[wave], lane, t, l0, nl);
     // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
     // transposed, four factors' 112-byte rows (three 160-byte ones with the remainder) go out per instruction
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
