@@ -196,6 +196,16 @@ def g6(ref):
     save('G6_fr1desk_5it', **out)
 
 
+def g10(ref):
+    """The reference's two other data files (SURVEY 8d "extra coverage"): fr2robot2 has different intrinsics
+    (K = 520.9, 521.0, 325.1, 249.7), fr1xyz_av is the second-largest file.  ba.py schedule, beliefs + ARE / energy trace."""
+    from gbp import gbp_ba
+    _, out = replay(gbp_ba, os.path.join(HERE, 'data', 'fr2robot2.txt'), 12, checkpoints=(4, 12))
+    save('G10_fr2robot2_12it', **out)
+    _, out = replay(gbp_ba, os.path.join(HERE, 'data', 'fr1xyz_av.txt'), 6, checkpoints=(6,))
+    save('G11_fr1xyz_av_6it', **out)
+
+
 def g7(ref):
     from gbp import gbp_ba
     bal = os.path.join(HERE, 'data', 'fr1desk_vsmall.txt')
@@ -248,7 +258,7 @@ def g9(ref):
          meas=prob.meas, cam_idx=prob.cam_idx, lmk_idx=prob.lmk_idx, **out)
 
 
-ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
+ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -123,6 +123,22 @@ def test_g6_fr1desk_config3(eng_mod, oracle_mod, fused):
 
 
 @pytest.mark.parametrize('fused', [False, True])
+def test_g10_g11_other_data_files(eng_mod, oracle_mod, fused):
+    """The reference's two other data files against the reference itself: fr2robot2 (different intrinsics; 12 sweeps of the
+    ba.py schedule incl. the relinearisations) and fr1xyz_av (6 sweeps)."""
+    g = golden('G10_fr2robot2_12it')
+    _, e = make(eng_mod, 'fr2robot2.txt', fused=fused)
+    snaps = {}
+    ares, energies = oracle_mod.replay_ba(e, 13, diagnostics=True, on_iter=lambda i, gr: snaps.__setitem__(i, gr.beliefs()) if i in (4, 12) else None)
+    assert np.allclose(ares[:12], g['are'], rtol=1e-6) and np.allclose(energies[:12], g['energy'], rtol=1e-5)
+    assert belief_gap(snaps[4], g, 'it4_') < BELIEF_TOL and belief_gap(snaps[12], g, 'it12_') < BELIEF_TOL
+    g = golden('G11_fr1xyz_av_6it')
+    _, e = make(eng_mod, 'fr1xyz_av.txt', fused=fused)
+    oracle_mod.replay_ba(e, 6)
+    assert belief_gap(e.beliefs(), g, 'it6_') < BELIEF_TOL
+
+
+@pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('loss', ['huber', 'constant'])
 def test_g7_robust_losses(eng_mod, oracle_mod, loss, fused):
     g = golden('G7_robust_vsmall')

@@ -143,6 +143,19 @@ def test_g6_fr1desk_5it(oracle_mod):
     assert belief_gap(o.beliefs(), g, 'it5_') < 1e-6
 
 
+def test_g10_g11_other_data_files(oracle_mod):
+    """fr2robot2 (its own intrinsics) and fr1xyz_av: the reference's remaining data files, ba.py schedule."""
+    g = golden('G10_fr2robot2_12it')
+    _, o = make(oracle_mod, 'fr2robot2.txt', threads=4)
+    ares, energies = oracle_mod.replay_ba(o, 4, diagnostics=True)
+    assert np.allclose(ares, g['are'][:4], rtol=1e-7) and np.allclose(energies, g['energy'][:4], rtol=1e-6)
+    assert belief_gap(o.beliefs(), g, 'it4_') < 1e-6
+    g = golden('G11_fr1xyz_av_6it')
+    _, o = make(oracle_mod, 'fr1xyz_av.txt', threads=4)
+    oracle_mod.replay_ba(o, 6)
+    assert belief_gap(o.beliefs(), g, 'it6_') < 1e-6
+
+
 @pytest.mark.parametrize('loss', ['huber', 'constant'])
 def test_g7_robust_losses(oracle_mod, loss):
     g = golden('G7_robust_vsmall')
