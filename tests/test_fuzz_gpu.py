@@ -97,7 +97,9 @@ def test_random_shapes_against_oracle(oracle_mod, seed):
             assert np.array_equal(so['iters_since_relin'], se['iters_since_relin'])
             assert np.array_equal(so['robust_flag'], se['robust_flag'])
             assert np.allclose(so['adaptive_var'], se['adaptive_var'], rtol=1e-6)
-            assert e.energy() == pytest.approx(o.energy(), rel=1e-6)
+            # (abs: graphs of a handful of factors can be fitted almost exactly -- residuals ~1e-3 px are differences of numbers
+            #  ~300 that agree to 1e-10 between the two implementations)
+            assert e.energy() == pytest.approx(o.energy(), rel=1e-6, abs=1e-8), (seed, 'energy')
         compared += 1
     assert compared >= 1, (seed, compared)
     COMPARED[seed] = compared
