@@ -200,6 +200,8 @@ def main():
         workload = "synthetic BAL"
     F, L, C = problem.n_factors, problem.n_lmks, problem.n_cams
 
+    # one node: the collectives' bootstrap sockets need no NIC and no resolvable hostname (the data path is xGMI either way)
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
     dist = None
     if world > 1 or dry or args.sharded:
         import torch.distributed as dist
