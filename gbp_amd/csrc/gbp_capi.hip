@@ -262,7 +262,8 @@ static int launch_cam_partial(gbp_ba *h, double *partial)
 static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, size_t stride)
 {
     if (!h->p.C) return GBP_OK;
-    hipLaunchKernelGGL(k_cam_finish, dim3((h->p.C + 63) / 64), dim3(64), 0, h->stream, h->p, gathered, n_parts, stride);
+    hipLaunchKernelGGL(k_cam_finish, dim3((h->p.C + FINISH_BLOCK / 64 - 1) / (FINISH_BLOCK / 64)), dim3(FINISH_BLOCK), 0, h->stream, h->p, gathered,
+                       n_parts, stride);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }

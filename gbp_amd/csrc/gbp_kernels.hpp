@@ -598,32 +598,35 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restr
     }
 }
 
-// belief_c = prior_c + sum over parts (fixed order) of part_r[c]; mu_c = Lambda^-1 eta.
-__global__ __launch_bounds__(64) void k_cam_finish(Params p, const double *__restrict__ gathered, int n_parts,
-                                                   size_t part_stride)
+// belief_c = prior_c + sum over parts (fixed order) of part_r[c]; mu_c = Lambda^-1 eta.  One wavefront per camera: lane k < 27
+// adds entry k of the parts (coalesced 216-byte rows) in rank order, lane 0 collects the 27 sums and solves the 6x6.
+constexpr int FINISH_BLOCK = 256;
+__global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const double *__restrict__ gathered, int n_parts,
+                                                              size_t part_stride)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= p.C) return;
-    double acc[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = p.cprior[(size_t)c * 27 + k];
-    for (int r = 0; r < n_parts; ++r) {
-        const double *src = gathered + (size_t)r * part_stride + (size_t)c * 27;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc[k] += src[k];
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (FINISH_BLOCK / 64) + (threadIdx.x >> 6);
+    if (c >= p.C) return;                                   // whole wave
+    double acc = 0.0;
+    if (lane < 27) {
+        acc = p.cprior[(size_t)c * 27 + lane];
+        for (int r = 0; r < n_parts; ++r) acc += gathered[(size_t)r * part_stride + (size_t)c * 27 + lane];
+        p.cbel[(size_t)c * CAMREC + CAM_ETA + lane] = acc;
     }
-    double *rec = p.cbel + (size_t)c * CAMREC;
+    double v[27];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) rec[CAM_ETA + k] = acc[k];
-    double eta[6], lam[21], mu[6];
+    for (int k = 0; k < 27; ++k) v[k] = __shfl(acc, k, 64);
+    if (lane == 0) {
+        double eta[6], lam[21], mu[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) eta[k] = acc[k];
+        for (int k = 0; k < 6; ++k) eta[k] = v[k];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) lam[k] = acc[6 + k];
-    spd_solve<6>(lam, eta, mu);
+        for (int k = 0; k < 21; ++k) lam[k] = v[6 + k];
+        spd_solve<6>(lam, eta, mu);
+        double *rec = p.cbel + (size_t)c * CAMREC;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
-    rec[33] = 0.0;
+        for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
+        rec[33] = 0.0;
+    }
 }
 
 // ----------------------------------------------------------------------------- diagnostics --
