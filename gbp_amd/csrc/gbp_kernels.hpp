@@ -256,27 +256,6 @@ GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], d
     for (int i = 0; i < 21; ++i) lam[i] = v[CAM_LAM + i];
 }
 
-// the same record in two gathers: mean | eta (what the relinearisation test and the linearisation need) and Lambda (needed
-// only when the cavity is formed) -- the second can be issued later, when fewer registers are live
-GBP_DEV void load_cam_head(const double *__restrict__ rec, double (&eta)[6], double (&mu)[6])
-{
-    const double2 *r2 = reinterpret_cast<const double2 *>(rec);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const double2 t = r2[i]; mu[2 * i] = t.x; mu[2 * i + 1] = t.y; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const double2 t = r2[3 + i]; eta[2 * i] = t.x; eta[2 * i + 1] = t.y; }
-}
-
-GBP_DEV void load_cam_lam(const double *__restrict__ rec, double (&lam)[21])
-{
-    const double2 *r2 = reinterpret_cast<const double2 *>(rec + CAM_LAM);
-    double v[22];
-#pragma unroll
-    for (int i = 0; i < 11; ++i) { const double2 t = r2[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
-#pragma unroll
-    for (int i = 0; i < 21; ++i) lam[i] = v[i];
-}
-
 // slot -> (valid, camera, landmark) through the tile table and the meta word
 GBP_DEV bool slot_info(const Params &p, int slot, int &cam, int &lmk)
 {
