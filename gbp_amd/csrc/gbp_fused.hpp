@@ -442,6 +442,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     const size_t shmem = fused_shmem(pl.group_cams);
     pl.pass_shmem = sizeof(double) * (size_t)(((pl.pass_cams * 27 + 1) & ~1) + 2);
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
+    if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
     std::vector<int32_t> blk((size_t)pl.n_blocks + 1);
     for (int b = 0; b <= pl.n_blocks; ++b) blk[b] = (int32_t)((int64_t)b * p.T / pl.n_blocks);
     int *d_blk = nullptr; double *d_bp = nullptr;
