@@ -29,7 +29,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU
   timeout 200 rocprofv3 --pmc $grp -f csv -d $OUT/sq_$i -o run -- $B --steps 6 --warmup 2 > $OUT/bench_sq_$i.log 2>&1
   echo "sq group $i ($grp) rc=$?"
 done
-for dbg in 0 1 4 5; do
+for dbg in 0 1 4 5 8 12 14; do
   GBP_FUSED_DBG=$dbg timeout 300 $B --steps 200 --warmup 20 > $OUT/bench_dbg$dbg.json 2> $OUT/bench_dbg$dbg.err
 done
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_general -o run -- $B --steps 100 --warmup 10 --no-fused > $OUT/bench_stats_general.log 2>&1

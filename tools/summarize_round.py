@@ -102,15 +102,17 @@ if sq:
     open(os.path.join(dst, f'{tag}_sq_counters.txt'), 'w').write('\n'.join(lines) + '\n')
 
 abl = []
-names = {0: 'full kernel', 1: 'no in-order wait before the camera accumulation', 4: 'no landmark-belief phase', 5: 'neither'}
-for dbg in (0, 1, 4, 5):
+names = {0: 'full kernel', 1: 'no in-order wait before the camera accumulation', 4: 'no landmark-belief phase', 5: 'neither',
+         8: 'camera records gathered from 8 cameras only (what a free gather would buy)', 12: 'cheap gather + no landmark-belief phase',
+         14: 'cheap gather + no landmark-belief phase + no camera accumulation: streams, maths and stores only'}
+for dbg in (0, 1, 4, 5, 8, 12, 14):
     ln = bench_line(os.path.join(out, f'bench_dbg{dbg}.json'))
     if ln:
         abl.append({"GBP_FUSED_DBG": dbg, "what": names[dbg], "kernel_avg_us": ln["roofline"]["kernel_avg_ms"] * 1e3,
                     "kernel_median_us": ln["roofline"]["kernel_median_ms"] * 1e3, "it_s": ln["value"]})
 if abl:
-    json.dump({"round": tag, "note": "timing only: the switched-off parts change the results (bit 2 = no accumulation is omitted: it changes convergence "
-                                     "and with it the relinearisation work)", "runs": abl}, open(os.path.join(dst, f'{tag}_ablations.json'), 'w'), indent=1)
+    json.dump({"round": tag, "note": "timing only: the switched-off parts change the results (bit 2 = no accumulation changes convergence and with it the "
+                                     "relinearisation work: compare medians)", "runs": abl}, open(os.path.join(dst, f'{tag}_ablations.json'), 'w'), indent=1)
 
 ln = bench_line(os.path.join(out, 'bench_default.json'))
 if ln:
