@@ -1,5 +1,8 @@
 """Randomised shapes, GPU engine (both sweeps) against the CPU oracle: tiny and lopsided graphs, landmarks from degree 1
-to several tiles, duplicate (camera, landmark) observations, every loss, random sweep flags.  Seeds are fixed."""
+to several tiles, duplicate (camera, landmark) observations, every loss, random sweep flags.  Seeds are fixed: 0 .. 23, or
+0 .. GBP_FUZZ_SEEDS - 1 for a longer soak (1000 seeds take a few minutes on the GPU box)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +12,7 @@ from gbp_amd.synthetic import BAProblem, make_synthetic
 pytestmark = pytest.mark.gpu
 
 COMPARED = {}
+N_SEEDS = int(os.environ.get('GBP_FUZZ_SEEDS', 24))
 
 
 def random_problem(seed):
@@ -66,7 +70,22 @@ def healthy(o, p, are0):
     return bool(ok) and o.are() < 1e3 * max(are0, 1.0)
 
 
-@pytest.mark.parametrize('seed', range(24))
+def third_opinion(p, cfg, flags_done, o):
+    """(belief spread, energy spread) between the C oracle and a third implementation of the same sweeps -- the object-per-
+    factor numpy restatement, np.linalg.inv like the reference.  The health filter above cannot see every ill-conditioned
+    state (2 of 1500 seeds: a relinearisation with residuals of ~40 px moves all three implementations 1e-6 apart from each
+    other in one sweep, tools/fuzz_diag.py): a GPU-oracle gap is a failure only if two CPU implementations agree better."""
+    from oracle.numpy_ba import NumpyBA
+    nb = NumpyBA(p, **cfg)
+    nb.generate_priors_var(30.0)
+    nb.update_all_beliefs()
+    for rob, rel in flags_done:
+        nb.synchronous_iteration(robustify=rob, local_relin=rel)
+    spread = max(rel_err_rows(a, b) for a, b in zip(nb.beliefs(), o.beliefs()))
+    return spread, abs(nb.energy() - o.energy()) / max(abs(o.energy()), 1e-300)
+
+
+@pytest.mark.parametrize('seed', range(N_SEEDS))
 def test_random_shapes_against_oracle(oracle_mod, seed):
     from gbp_amd.engine import BAEngine
     rng = np.random.default_rng(seed)
@@ -84,22 +103,27 @@ def test_random_shapes_against_oracle(oracle_mod, seed):
         g.update_all_beliefs()
     are0 = o.are()
     compared = 0
-    for rob, rel in flags:
+    for k, (rob, rel) in enumerate(flags):
         for g in [o] + engines:
             g.synchronous_iteration(robustify=rob, local_relin=rel)
         if not healthy(o, p, are0):
             break
         ob, so = o.beliefs(), o.relin_state()
+        gaps = [max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), ob)) for e in engines]
+        # (abs: graphs of a handful of factors can be fitted almost exactly -- residuals ~1e-3 px are differences of numbers
+        #  ~300 that agree to 1e-10 between the two implementations)
+        egaps = [abs(e.energy() - o.energy()) for e in engines]
+        etol = max(1e-6 * abs(o.energy()), 1e-8)
+        if max(gaps) >= 1e-6 or max(egaps) > etol:
+            spread, espread = third_opinion(p, cfg, flags[:k + 1], o)
+            assert max(gaps) < max(1e-6, 4.0 * spread), (seed, compared, gaps, spread, p.n_cams, p.n_lmks, p.n_factors)
+            assert max(egaps) <= max(etol, 4.0 * espread * abs(o.energy())), (seed, 'energy', egaps, espread)
+            break                                           # ill-conditioned from here on: nothing more to learn from this seed
         for e in engines:
-            gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), ob))
-            assert gap < 1e-6, (seed, compared, gap, p.n_cams, p.n_lmks, p.n_factors)
             se = e.relin_state()
             assert np.array_equal(so['iters_since_relin'], se['iters_since_relin'])
             assert np.array_equal(so['robust_flag'], se['robust_flag'])
             assert np.allclose(so['adaptive_var'], se['adaptive_var'], rtol=1e-6)
-            # (abs: graphs of a handful of factors can be fitted almost exactly -- residuals ~1e-3 px are differences of numbers
-            #  ~300 that agree to 1e-10 between the two implementations)
-            assert e.energy() == pytest.approx(o.energy(), rel=1e-6, abs=1e-8), (seed, 'energy')
         compared += 1
     assert compared >= 1, (seed, compared)
     COMPARED[seed] = compared
@@ -107,4 +131,4 @@ def test_random_shapes_against_oracle(oracle_mod, seed):
 
 def test_fuzz_was_not_vacuous():
     """Most sweeps of most seeds must have been comparable (the health filter may only cut the odd blown-up run short)."""
-    assert len(COMPARED) == 24 and sum(COMPARED.values()) >= 0.6 * 8 * 24, COMPARED
+    assert len(COMPARED) == N_SEEDS and sum(COMPARED.values()) >= 0.6 * 8 * N_SEEDS, COMPARED
