@@ -235,6 +235,14 @@ class ShardedBA:
         self.shard.sync()
         return t.cpu().numpy()
 
+    def count_relinearising(self):
+        """Factors with iters_since_relin == 0 (what ba.py:96-99 counts after every sweep), over all ranks."""
+        with self._ctx():
+            t = self.shard.to_tensor(np.array([float(self.engine.count_relinearising())]))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.shard.sync()
+        return int(round(float(t.cpu().numpy()[0])))
+
     def close(self):
         if self.library_loop:
             self.engine.comm_destroy()
