@@ -35,3 +35,11 @@ print(f"waves {nr.value}; ticks per wave: mean {tot.mean():.0f} min {tot.min():.
 share = out.astype(np.float64).sum(axis=0) / tot.sum()
 for n, s, m in zip(NAMES, share, out.astype(np.float64).mean(axis=0)):
     print(f"  {n:34s} {100 * s:5.1f} %   {m:9.0f} ticks/wave")
+# per-workgroup finishing time (its slowest wave): the kernel lasts as long as the slowest workgroup
+wg = tot.reshape(-1, 8).max(axis=1)
+print(f"workgroups {wg.size}: finishing ticks mean {wg.mean():.0f} min {wg.min():.0f} max {wg.max():.0f}  (max / mean = {wg.max() / wg.mean():.3f})")
+for x in range(8):
+    s = wg[x::8]
+    print(f"  workgroups = {x} mod 8 (one XCD): mean {s.mean():.0f} min {s.min():.0f} max {s.max():.0f}")
+order = np.argsort(wg)
+print("  slowest workgroups:", [(int(b), int(wg[b])) for b in order[-8:]], " fastest:", [(int(b), int(wg[b])) for b in order[:4]])
