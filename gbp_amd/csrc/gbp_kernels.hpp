@@ -178,45 +178,67 @@ GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2],
     const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
     Lin L;
     factor_linearise(p, x0, z, avar, d, L);
-    // cavities: belief minus this factor's OLD message, which lives in the span of the OLD Jacobian
-    double ceC[6], eLold[3];
+    // Each elimination works on  belief - this factor's OLD message + the factor's own block.  The old message lives in the span
+    // of the OLD Jacobian (M = J^T Q J, e = J^T q).  A factor that keeps its linearisation point -- every factor of most sweeps --
+    // folds the two terms:  Lambda_C - Jc^T W Jc + s Jc^T Jc = Lambda_C + Jc^T (sI - W) Jc  and  eta_C - Jc^T q + s Jc^T rho =
+    // eta_C + Jc^T (s rho - q): one rank-2 update per block instead of two.  One that relinearises (or carries a dense
+    // remainder) takes the old message out first, with the old Jacobian.
+    const bool two_step = XTRA || relin;
+    double uC[6], eLold[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ceC[i] = etaC[i] - (L.Jc[0][i] * qC[0] + L.Jc[1][i] * qC[1]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) eLold[i] = L.Jl[0][i] * qL[0] + L.Jl[1][i] * qL[1];
-    rank2_update<6>(clC, L.Jc[0], L.Jc[1], WC, -1.0);
-    rank2_update<3>(clL, L.Jl[0], L.Jl[1], VL, -1.0);
+    for (int i = 0; i < 6; ++i) uC[i] = etaC[i];
     double xn[XTRA ? XTRA_ROW : 1];
-    if (XTRA) {
-        // e_old = J_old^T q_old + x_old.  Damped in the very sweep it relinearises: d e_old leaves the span of the new
-        // Jacobian and is carried densely; otherwise only the old remainder decays.
+    if (two_step) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double eo = etaC[i] - ceC[i] + xt[i];            // the old dense message to the camera
-            ceC[i] -= xt[i];
-            xn[i] = relin ? d * eo : d * xt[i];
+        for (int i = 0; i < 6; ++i) uC[i] -= L.Jc[0][i] * qC[0] + L.Jc[1][i] * qC[1];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) eLold[i] = L.Jl[0][i] * qL[0] + L.Jl[1][i] * qL[1];
+        rank2_update<6>(clC, L.Jc[0], L.Jc[1], WC, -1.0);
+        rank2_update<3>(clL, L.Jl[0], L.Jl[1], VL, -1.0);
+        if (XTRA) {
+            // e_old = J_old^T q_old + x_old.  Damped in the very sweep it relinearises: d e_old leaves the span of the new
+            // Jacobian and is carried densely; otherwise only the old remainder decays.
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double eo = etaC[i] - uC[i] + xt[i];             // the old dense message to the camera
+                uC[i] -= xt[i];
+                xn[i] = relin ? d * eo : d * xt[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                eLold[i] += xt[6 + i];
+                xn[6 + i] = relin ? d * eLold[i] : d * xt[6 + i];
+            }
+            if (relin) { qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0; }
         }
+        if (relin) {                                       // gbp.py:75-78: linearise again at the belief means
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            eLold[i] += xt[6 + i];
-            xn[6 + i] = relin ? d * eLold[i] : d * xt[6 + i];
+            for (int i = 0; i < 6; ++i) x0[i] = muC[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
+            factor_linearise(p, x0, z, avar, d, L);
         }
-        if (relin) { qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0; }
     }
-    if (relin) {                                           // gbp.py:75-78: linearise again at the belief means
-#pragma unroll
-        for (int i = 0; i < 6; ++i) x0[i] = muC[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
-        factor_linearise(p, x0, z, avar, d, L);
+    // the factor's own block (minus the folded old message): cores of the rank-2 terms and coefficients of the eta terms
+    const double s = L.s;
+    double cW[3] = {s, 0.0, s}, cV[3] = {s, 0.0, s}, rC[2] = {s * L.rho[0], s * L.rho[1]}, rL[2] = {rC[0], rC[1]};
+    if (!two_step) {
+        cW[0] -= WC[0]; cW[1] -= WC[1]; cW[2] -= WC[2];
+        cV[0] -= VL[0]; cV[1] -= VL[1]; cV[2] -= VL[2];
+        rC[0] -= qC[0]; rC[1] -= qC[1];
+        rL[0] -= qL[0]; rL[1] -= qL[1];
     }
+    rank2_update<6>(clC, L.Jc[0], L.Jc[1], cW, 1.0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) uC[i] += L.Jc[0][i] * rC[0] + L.Jc[1][i] * rC[1];
     double qLn[2];
-    message_to_landmark_cavity(L, ceC, clC, qL, qLn, eLn, MLn, VL);
-    double ceL[3];                                         // fetched only now: three doubles less through the 6x6 elimination
-    lmk_belief_eta(ceL);
+    message_to_landmark(L, uC, clC, qL, qLn, eLn, MLn, VL);
+    double gL[3];                                          // fetched only now: three doubles less through the 6x6 elimination
+    lmk_belief_eta(gL);
+    rank2_update<3>(clL, L.Jl[0], L.Jl[1], cV, 1.0);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ceL[i] -= eLold[i];
-    message_to_camera_cavity(L, ceL, clL, qC, eCn, MCn, WC);
+    for (int i = 0; i < 3; ++i) gL[i] += L.Jl[0][i] * rL[0] + L.Jl[1][i] * rL[1] - eLold[i];
+    message_to_camera(L, gL, clL, qC, eCn, MCn, WC);
     qL[0] = qLn[0]; qL[1] = qLn[1];
     if (XTRA) {
 #pragma unroll

@@ -283,24 +283,19 @@ struct Lin {
 
 // Message to the LANDMARK: eliminate the camera block (6x6).   Factor.compute_messages, v = 1  gbp.py:340-368
 //   cavity of the camera: cetaC = eta_C - e_C, clamC = Lambda_C - M_C (belief minus this factor's OLD message)
-//   T = s Jc^T Jc + clamC,  u = s Jc^T rho + cetaC
+//   T = s Jc^T Jc + clamC,  u = s Jc^T rho + cetaC          (assembled by the caller: factor_core, gbp_kernels.hpp)
 //   M_L' = Jl^T (sI - s^2 Jc T^-1 Jc^T) Jl,  e_L' = (1-d) s Jl^T (rho - Jc T^-1 u) + d e_L
 // The forward substitutions of Jc^T and u ride along with the LDL^T elimination (augmented columns) and the
 // 2x2 quadratic forms are accumulated pivot by pivot, so nothing but the shrinking trailing block stays live.
 //   qLold / qLnew: coefficients of the message eta in the rows of Jl (e_L = Jl^T q_L), eLnew = the dense new eta
-GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], double (&clamC)[21],
-                                        const double (&qLold)[2], double (&qLnew)[2], double (&eLnew)[3], double (&MLnew)[6],
-                                        double (&Vcore)[3])
+GBP_DEV void message_to_landmark(const Lin &L, double (&u)[6], double (&clamC)[21],
+                                 const double (&qLold)[2], double (&qLnew)[2], double (&eLnew)[3], double (&MLnew)[6],
+                                 double (&Vcore)[3])
 {
     const double s = L.s;
-    double y0[6], y1[6], u[6];
+    double y0[6], y1[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        y0[i] = L.Jc[0][i]; y1[i] = L.Jc[1][i];
-        u[i] = s * (L.Jc[0][i] * L.rho[0] + L.Jc[1][i] * L.rho[1]) + cetaC[i];
-#pragma unroll
-        for (int j = i; j < 6; ++j) clamC[Sym<6>::at(i, j)] += s * (L.Jc[0][i] * L.Jc[0][j] + L.Jc[1][i] * L.Jc[1][j]);
-    }
+    for (int i = 0; i < 6; ++i) { y0[i] = L.Jc[0][i]; y1[i] = L.Jc[1][i]; }
     double H00 = 0.0, H01 = 0.0, H11 = 0.0, k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -337,20 +332,15 @@ GBP_DEV void message_to_landmark_cavity(const Lin &L, const double (&cetaC)[6], 
 
 // Message to the CAMERA: eliminate the landmark block (3x3).   Factor.compute_messages, v = 0  gbp.py:340-368
 //   cavity of the landmark: cetaL = eta_L - e_L, clamL = Lambda_L - M_L (OLD landmark message)
-//   S = s Jl^T Jl + clamL,  g = s Jl^T rho + cetaL
+//   S = s Jl^T Jl + clamL,  g = s Jl^T rho + cetaL          (assembled by the caller)
 //   M_C' = Jc^T (sI - s^2 Jl S^-1 Jl^T) Jc,  e_C' = (1-d) s Jc^T (rho - Jl S^-1 g) + d e_C = Jc^T q_C'   (qC in: old, out: new)
-GBP_DEV void message_to_camera_cavity(const Lin &L, const double (&cetaL)[3], double (&clamL)[6],
-                                      double (&qC)[2], double (&eCnew)[6], double (&MCnew)[21], double (&Wcore)[3])
+GBP_DEV void message_to_camera(const Lin &L, double (&g)[3], double (&clamL)[6],
+                               double (&qC)[2], double (&eCnew)[6], double (&MCnew)[21], double (&Wcore)[3])
 {
     const double s = L.s;
-    double y0[3], y1[3], g[3];
+    double y0[3], y1[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        y0[i] = L.Jl[0][i]; y1[i] = L.Jl[1][i];
-        g[i] = s * (L.Jl[0][i] * L.rho[0] + L.Jl[1][i] * L.rho[1]) + cetaL[i];
-#pragma unroll
-        for (int j = i; j < 3; ++j) clamL[Sym<3>::at(i, j)] += s * (L.Jl[0][i] * L.Jl[0][j] + L.Jl[1][i] * L.Jl[1][j]);
-    }
+    for (int i = 0; i < 3; ++i) { y0[i] = L.Jl[0][i]; y1[i] = L.Jl[1][i]; }
     double G00 = 0.0, G01 = 0.0, G11 = 0.0, k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
