@@ -32,6 +32,12 @@
 // against 84 us: the time moved into the issue of the stores and the in-order accumulation wait (23 % + 25 %) -- the vector-memory
 // path of the CU (camera gathers: 17 x 64 different lines per tile, streams, stores) and HBM are the limit, not latency.
 //
+// Also measured and not kept: knowing a wave's NEXT tile one iteration early (ticket, descriptor and meta word fetched during
+// the current tile, so that streams and camera gather leave in one go instead of after two dependent round trips): 89 us with the
+// lookahead alone, 92-94 us with the gather issued up-front (256 VGPRs, one spill) against 81 us.  A wave that commits to its next
+// tile early takes away what the ticket counter is for -- whichever wave is free takes the next tile -- and every other wave of
+// the workgroup then waits for it at the in-order accumulation.
+//
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
 // (C > 516) the cameras are split into two groups (516 + up to 758): the sweep adds up the first, k_cam_pass the others; beyond that the
