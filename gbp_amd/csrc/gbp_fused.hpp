@@ -38,6 +38,14 @@
 // tile early takes away what the ticket counter is for -- whichever wave is free takes the next tile -- and every other wave of
 // the workgroup then waits for it at the in-order accumulation.
 //
+// The camera accumulation is the most expensive thing left on chip (round 2, same box, alternating runs): doing it TWICE (halves)
+// costs +22 us of 82; only its first round (GBP_FUSED_DBG=32: the ~6 % of a tile's factors that share a camera with an earlier
+// lane are dropped) saves 6 us; the same adds as explicit ds_read / v_add / ds_write instead of ds_add_f64 -- legal, since one
+// wave at a time adds and the lanes of a round hit different cameras -- cost +9 us (the read's round trip lands inside the
+// ordered section, the no-return atomics only have to be issued).  64 random cameras per instruction fall on 32 bank pairs, about
+// three times the conflict-free LDS time; a transposed accumulation (27 lanes per factor, consecutive banks) would need the 27
+// values of a factor in LDS first, and there is no LDS left next to the table (500 cameras: 156 of 160 KB).
+//
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
 // (C > 516) the cameras are split into two groups (516 + up to 758): the sweep adds up the first, k_cam_pass the others; beyond that the
@@ -62,7 +70,8 @@ struct FusedArgs {
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
     int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase,
-                                // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results)
+                                // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results),
+                                // 32 only the first round of the accumulation (same-camera duplicates of a tile dropped)
     unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
 };
 
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         const int rank = state_rank(st);
         const int cloc = cam - a.cam_base;                 // (cameras of later groups are added up by k_cam_pass)
         const bool mine = active && (unsigned)cloc < (unsigned)a.cam_count;
-        for (int r = 0; r <= maxrank; ++r) {
+        for (int r = 0; r <= ((a.dbg & 32) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
             if (mine && rank == r && !(a.dbg & 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
                 double *dst = acc + cloc * 27;
 #pragma unroll
