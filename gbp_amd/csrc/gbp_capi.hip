@@ -571,7 +571,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     {
         const int n_wg = std::max(1, std::min(T, n_cus));
         const size_t need = S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
-                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * 27 * sizeof(double)
+                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
                           + (size_t)std::max(C, 1) * (CAMREC + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
                           + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);

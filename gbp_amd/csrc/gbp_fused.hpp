@@ -59,13 +59,14 @@
 namespace gbp {
 
 constexpr int LDS_BYTES = 160 * 1024;
+constexpr int TROW = 28;                            // doubles per row of the workgroup tables in HBM (27 + pad: 16-byte stores / loads)
 constexpr int WAT_WAVES = 8;
 constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][24] landmark records, then [64][9] messages
 constexpr int WAVE_PRIOR_DOUBLES = TILE_LMKS * LPRI;
 static_assert(TILE_LMKS * LREC <= WAVE_LDS_DOUBLES, "landmark records of a tile must fit the wave scratch");
 
 struct FusedArgs {
-    double *block_partials;     // [C][n_blocks][27]
+    double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes
     int acc_doubles;            // cameras of the group * 27
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
     int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
@@ -249,9 +250,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
     __syncthreads();
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
-    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
-        const int c = i / 27, k = i - c * 27;
-        a.block_partials[((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * 27 + k] = acc[i];
+    for (int i = tid; i < (a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
+        const int c = i / (TROW / 2), k = 2 * (i - c * (TROW / 2));
+        const double2 v = make_double2(acc[c * 27 + k], k + 1 < 27 ? acc[c * 27 + k + 1] : 0.0);
+        *reinterpret_cast<double2 *>(a.block_partials + ((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * TROW + k) = v;
     }
 }
 
@@ -317,9 +319,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a,
         if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) {
-        const int c = i / 27, k = i - c * 27;
-        a.block_partials[((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * 27 + k] = acc[i];
+    for (int i = tid; i < (a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
+        const int c = i / (TROW / 2), k = 2 * (i - c * (TROW / 2));
+        const double2 v = make_double2(acc[c * 27 + k], k + 1 < 27 ? acc[c * 27 + k + 1] : 0.0);
+        *reinterpret_cast<double2 *>(a.block_partials + ((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * TROW + k) = v;
     }
 }
 
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
                                                                  double *__restrict__ partial, int finish)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][27] | red[RED_PARTS][27] | tot[27]
-    const int c = blockIdx.x, n = n_blocks * 27, tid = threadIdx.x;
+    const int c = blockIdx.x, n = n_blocks * TROW, tid = threadIdx.x;
     double *red = sh + ((n + 1) & ~1), *tot = red + RED_PARTS * 27;
     const double *src = block_partials + (size_t)c * n;
     if (((size_t)c * n & 1) == 0) {
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     if (tid < RED_PARTS * 27) {
         const int part = tid / 27, k = tid - part * 27;
         double s = 0.0;
-        for (int b = part; b < n_blocks; b += RED_PARTS) s += sh[b * 27 + k];
+        for (int b = part; b < n_blocks; b += RED_PARTS) s += sh[b * TROW + k];
         red[part * 27 + k] = s;
     }
     __syncthreads();
@@ -462,7 +465,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     for (int b = 0; b <= pl.n_blocks; ++b) blk[b] = (int32_t)((int64_t)b * p.T / pl.n_blocks);
     int *d_blk = nullptr; double *d_bp = nullptr;
     if (fused_upload(pl, &d_blk, blk.data(), blk.size(), stream)) return -1;
-    if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * 27, stream)) return -1;
+    if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * TROW, stream)) return -1;
     pl.n_big = (int)big.size();
     if (pl.n_big && fused_upload(pl, &pl.d_big, big.data(), big.size(), stream)) return -1;
     const char *env_dbg = getenv("GBP_FUSED_DBG");
@@ -481,7 +484,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pass_shmem) != hipSuccess) return -1;
 #undef GBP_SET_SHMEM
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
+                            (int)(sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
     pl.enabled = true;
     return 0;
 }
@@ -509,7 +512,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
         hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.pass_shmem, stream, p, ag, p.tiles, pl.d_blk);
     }
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
-    const size_t red_shmem = sizeof(double) * ((size_t)((pl.n_blocks * 27 + 1) & ~1) + (RED_PARTS + 1) * 27);
+    const size_t red_shmem = sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27);
     hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);
     return (int)hipGetLastError();
 }
