@@ -367,7 +367,7 @@ GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, double *wp, int 
 template <int LOSS, bool XTRA>
 __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 {
-    __shared__ double wls[BLOCK / 64][WTILE * CSTAGE_ROW];  // per wave: [64][9] landmark messages, then [64][20] camera-message rows
+    __shared__ __attribute__((aligned(16))) double wls[BLOCK / 64][WTILE * CSTAGE_ROW];  // per wave: [64][9] landmark messages, then [64][20] camera-message rows
     __shared__ int wps[BLOCK / 64][WTILE];
     __shared__ double wprs[BLOCK / 64][TILE_LMKS * LPRI];   // per wave: prior | rows of the tile's landmarks
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -449,18 +449,20 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     wave_lds_sync();                                        // the wave's LDS writes are done (one wave: no barrier needed)
     tile_landmark_beliefs(p, wl, wprs[wave], lane, t, l0, nl);
     // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
-    // transposed, four factors' 112-byte rows (three 160-byte ones with the remainder) go out per instruction
+    // transposed, whole rows go out, 16 bytes per lane
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
-    constexpr int R = XTRA ? CSTAGE_ROW : CSTAGE_USED, PER = 64 / R;
+    constexpr int R = XTRA ? CSTAGE_ROW : CSTAGE_USED;
     if (active) {
 #pragma unroll
         for (int k = 0; k < R; ++k) wl[lane * R + k] = srow[k];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-        const int g = lane / R, k = lane - g * R;
-        if (g < PER) {
-            for (int f = g; f < nf; f += PER) p.cstage[(size_t)wp[f] * CSTAGE_ROW + k] = wl[f * R + k];
+        constexpr int R2 = R / 2, PER2 = 64 / R2;           // 16 bytes per lane: nine 112-byte rows per instruction (six 160-byte ones)
+        const int g = lane / R2, k = 2 * (lane - g * R2);
+        if (g < PER2) {
+            for (int f = g; f < nf; f += PER2)
+                *reinterpret_cast<double2 *>(p.cstage + (size_t)wp[f] * CSTAGE_ROW + k) = *reinterpret_cast<const double2 *>(wl + f * R + k);
         }
     }
 }
