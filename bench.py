@@ -50,9 +50,10 @@ def survey_bytes(F, L, C):
 def layout_bytes(F, L, C, n_blocks, fused):
     """Bytes one launch of the dominant kernel must move in THIS engine's layout."""
     if fused:       # k_sweep_wat: x0 9 z 2 | msgs 10 in, 10 out | meta 4 B, state 4 B in + 4 B out; landmark record 24 in, belief+mean 12 out; tables out
-        return F * ((21 + 10) * 8 + 12) + L * (24 + 12) * 8 + n_blocks * C * 27 * 8
-    # k_factor_tile: the same per-factor / per-landmark streams + the dense camera message staged camera-major (27 doubles + cpos)
-    return F * ((21 + 10) * 8 + 12 + 27 * 8 + 4) + L * (24 + 12) * 8
+        return F * ((21 + 10) * 8 + 12) + L * (24 + 12) * 8 + n_blocks * C * 28 * 8      # (table rows: 27 sums + 1 pad double)
+    # k_factor_tile: the same per-factor / per-landmark streams + what rebuilds the camera message, staged camera-major
+    # (x0 9 | q_C 2 | W 3 = 14 doubles, + cpos)
+    return F * ((21 + 10) * 8 + 12 + 14 * 8 + 4) + L * (24 + 12) * 8
 
 
 def host_cores():
