@@ -132,11 +132,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         GBP_PH(0);                                         // ticket + descriptor
 
         // the tile's landmark records (belief | mean | prior | rows) are one contiguous run: the wave fetches it whole
-        const int nrec = valid ? max(nl, 1) * LREC : 0;    // chunk tiles stage the over-sized landmark td.x
-        const double *lsrc = p.lrec + (size_t)l0 * LREC;
-        double stage[WAVE_LDS_DOUBLES / 64];
+        const int nrec2 = valid ? max(nl, 1) * (LREC / 2) : 0;    // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
+        const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
+        constexpr int NSTAGE = (WAVE_LDS_DOUBLES / 2 + 63) / 64;
+        double2 stage[NSTAGE];
 #pragma unroll
-        for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) stage[j] = (j * 64 + lane < nrec) ? lsrc[j * 64 + lane] : 0.0;
+        for (int j = 0; j < NSTAGE; ++j) stage[j] = (j * 64 + lane < nrec2) ? lsrc[j * 64 + lane] : make_double2(0.0, 0.0);
 
         // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
 
         // landmark records -> wave scratch -> the lanes of their factors; priors | rows -> wp for the tail
 #pragma unroll
-        for (int j = 0; j < WAVE_LDS_DOUBLES / 64; ++j) wl[j * 64 + lane] = stage[j];
+        for (int j = 0; j < NSTAGE; ++j)
+            if (j * 64 + lane < WAVE_LDS_DOUBLES / 2) reinterpret_cast<double2 *>(wl)[j * 64 + lane] = stage[j];
         wave_lds_sync();
         double muL[3], clL[6];
         if (active) {
