@@ -44,7 +44,9 @@
 // wave at a time adds and the lanes of a round hit different cameras -- cost +9 us (the read's round trip lands inside the
 // ordered section, the no-return atomics only have to be issued).  64 random cameras per instruction fall on 32 bank pairs, about
 // three times the conflict-free LDS time; a transposed accumulation (27 lanes per factor, consecutive banks) would need the 27
-// values of a factor in LDS first, and there is no LDS left next to the table (500 cameras: 156 of 160 KB).
+// values of a factor in LDS first, and there is no LDS left next to the table (500 cameras: 156 of 160 KB).  Splitting the
+// ordered section into three (nine entries each, a turn counter per third, so that three waves can be inside): 84.7 against
+// 79.5 us per step -- the ordered section is not what the waves queue for, two more hand-overs per tile only cost.
 //
 // Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
 // and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
