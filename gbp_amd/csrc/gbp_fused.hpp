@@ -80,9 +80,9 @@ struct FusedArgs {
 
 // Phase profile of the persistent loop (tools/phase_profile.py builds the library with -DGBP_PHASE_TIMING): every wave adds
 // the s_memtime ticks it spends between consecutive marks into its own row.  Off in the product build (no code at all).
-constexpr int NPHASE = 10;
+constexpr int NPHASE = 12;
 #ifdef GBP_PHASE_TIMING
-#define GBP_PH_DECL unsigned long long ph_last = __builtin_amdgcn_s_memtime(), ph_acc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define GBP_PH_DECL unsigned long long ph_last = __builtin_amdgcn_s_memtime(), ph_acc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define GBP_PH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
                        ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
 #define GBP_PH_NOWAIT(i) do { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
@@ -251,14 +251,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         pend = true; q_t = t; q_l0 = l0; q_nl = nl;
     }
     if (lane == 0) relin_add(p, n_relin);
-    GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
+    GBP_PH_NOWAIT(9);
     __syncthreads();
+    GBP_PH_NOWAIT(10);                                     // waiting for the other waves of the workgroup
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
     for (int i = tid; i < (a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
         const int c = i / (TROW / 2), k = 2 * (i - c * (TROW / 2));
         const double2 v = make_double2(acc[c * 27 + k], k + 1 < 27 ? acc[c * 27 + k + 1] : 0.0);
         *reinterpret_cast<double2 *>(a.block_partials + ((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * TROW + k) = v;
     }
+    GBP_PH(11);                                            // table write-out
+    GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
 }
 
 // More cameras than one LDS table holds (C > 516): the sweep above adds up the messages to the first group of cameras; one

@@ -9,7 +9,7 @@ import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); REPO = os.path.dirname(HERE)
 LIB = os.path.join(HERE, 'libgbp_phase.so')
 NAMES = ['ticket+descriptor', 'issue stream loads', 'lmk beliefs of prev tile (LDS)', 'wait streams', 'camera gather', 'lmk records via LDS',
-         'maths', 'stores issued', 'wait accumulation turn', 'accumulate + loop']
+         'maths', 'stores issued', 'wait accumulation turn', 'accumulate + loop', 'wait for the other waves at the end', 'table write-out']
 if not os.path.exists(LIB) or '--build-only' in sys.argv:
     csrc = os.path.join(REPO, 'gbp_amd', 'csrc')
     subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DGBP_PHASE_TIMING',
