@@ -39,7 +39,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 MIN_TIMED_S = 0.5
-MAX_BATCHES = 64
+MAX_BATCHES = 2000          # (a 20-step batch of a 15 us sweep is 0.3 ms: the cap only bounds degenerate cases)
 
 
 def survey_bytes(F, L, C):
