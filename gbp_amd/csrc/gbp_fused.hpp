@@ -380,16 +380,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     }
     if (!finish) return;
     __syncthreads();
+    double *rec = p.cbel + (size_t)c * CAMREC;
+    if (tid >= 64 && tid < 64 + 27) rec[CAM_ETA + tid - 64] = tot[tid - 64];      // eta | Lambda: one store instruction of another wave
     if (tid == 0) {
-        double *rec = p.cbel + (size_t)c * CAMREC;
         double eta[6], lam[21], mu[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { eta[k] = tot[k]; rec[CAM_ETA + k] = tot[k]; }
+        for (int k = 0; k < 6; ++k) eta[k] = tot[k];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) { lam[k] = tot[6 + k]; rec[CAM_ETA + 6 + k] = tot[6 + k]; }
+        for (int k = 0; k < 21; ++k) lam[k] = tot[6 + k];
         spd_solve<6>(lam, eta, mu);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
+        double2 *r2 = reinterpret_cast<double2 *>(rec + CAM_MU);
+        r2[0] = make_double2(mu[0], mu[1]); r2[1] = make_double2(mu[2], mu[3]); r2[2] = make_double2(mu[4], mu[5]);
         rec[33] = 0.0;
     }
 }
