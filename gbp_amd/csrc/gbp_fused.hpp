@@ -132,9 +132,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         const bool active = lane < nf;
         const int slot = t * WTILE + lane;
         GBP_PH(0);                                         // ticket + descriptor
+        if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
+            if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, wp, lane, q_t, q_l0, q_nl);
+            GBP_PH_NOWAIT(2);
+            break;
+        }
 
         // the tile's landmark records (belief | mean | prior | rows) are one contiguous run: the wave fetches it whole
-        const int nrec2 = valid ? max(nl, 1) * (LREC / 2) : 0;    // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
+        const int nrec2 = max(nl, 1) * (LREC / 2);         // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
         const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
         constexpr int NSTAGE = (WAVE_LDS_DOUBLES / 2 + 63) / 64;
         double2 stage[NSTAGE];
@@ -171,8 +176,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         load_cam_record(p.cbel + (size_t)((a.dbg & 8) ? (cam & 7) : cam) * CAMREC, etaC, clC, muC);   // (dbg 8: what would a cheap gather buy?)
         asm volatile("" ::: "memory");
         GBP_PH(4);                                         // camera gather
-
-        if (!valid) break;
 
         // landmark records -> wave scratch -> the lanes of their factors; priors | rows -> wp for the tail
 #pragma unroll
