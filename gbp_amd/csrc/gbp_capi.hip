@@ -102,6 +102,7 @@ struct gbp_ba {
     // enters it, so the last RELIN_RING/2 sweeps are always readable
     int *d_relin_ring = nullptr;
     long sweep_count = 0;                        // sweeps since create (index into the relin ring)
+    uint32_t gen_parity = 0;                     // general sweep: direction of the walk (not part of the state: the sums do not depend on it)
     uint32_t walk_parity = 0;                    // part of the STATE: odd sweeps walk the tiles backwards, so a restored handle must
                                                  // resume with the parity it was saved with to continue bit-identically
     int *d_count = nullptr;                      // scratch counter of gbp_ba_count_relinearising / gbp_ba_check_layout
@@ -271,8 +272,7 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
 // camera-major staging of the general sweep, allocated on first use (F x 27 doubles; the slot -> row map cpos is made by the build)
 static int ensure_staging(gbp_ba *h)
 {
-    if (h->p.cstage) return GBP_OK;
-    CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * CSTAGE_ROW));
+    if (!h->p.cstage) CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * CSTAGE_ROW));
     if (!h->big_lmks.empty() && !h->d_big) {
         CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
         CHK(upload(h, h->d_big, h->big_lmks));
@@ -324,7 +324,11 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         return GBP_OK;
     }
     if (with_messages) {
-        // tile sweep: messages + the tiles' landmark beliefs + camera messages staged camera-major
+        // tile sweep: messages + the tiles' landmark beliefs + camera messages staged camera-major.  Every other sweep backwards,
+        // like the fused sweep (what the memory-side cache still holds is used first; the results do not depend on the order)
+        static const bool no_rev_g = getenv("GBP_NO_REVERSE") != nullptr;
+        h->p.reverse_walk = no_rev_g ? 0 : (int)(h->gen_parity & 1u);
+        h->gen_parity ^= 1u;
         CHK(ensure_staging(h));
         CHK(launch_factor_stage(h, robustify, local_relin));
         if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
@@ -568,15 +572,19 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     clk.mark("tile packing");
     // 5. per-slot data
     unsigned *d_meta = nullptr;
+    bool general_sweep = false;
     {
         const int n_wg = std::max(1, std::min(T, n_cus));
-        const size_t need = S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
+        const int cgmax = fused_max_cams() + (MAX_CAM_GROUPS - 1) * pass_max_cams();
+        general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
+        const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * CSTAGE_ROW * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
                           + (size_t)std::max(C, 1) * (CAMREC + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
                           + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);
         CHK(arena_reserve(h, need));
     }
+    if (general_sweep && F > 0) CHK(dev_alloc(h, &p.cstage, Fz * CSTAGE_ROW));   // out of the same arena (else: on first use, ensure_staging)
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
     if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));

@@ -70,6 +70,7 @@ struct Params {
     const int *cpos;              // slot -> row of cstage
     double *xtra;                 // [slot][9] out-of-span remainder of the message etas, or NULL (gbp_math.hpp header: only when
                                   // num_undamped_iters = 0 lets a factor be damped in the sweep it relinearises in)
+    int reverse_walk;             // general sweep: tiles and cameras are visited backwards (every other sweep; results do not depend on it)
     int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
 };
 
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     __shared__ int wps[BLOCK / 64][WTILE];
     __shared__ double wprs[BLOCK / 64][TILE_LMKS * LPRI];   // per wave: prior | rows of the tile's landmarks
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int t = blockIdx.x * (BLOCK / 64) + wave;
+    int t = blockIdx.x * (BLOCK / 64) + wave;
     if (t >= p.T) return;                                   // whole wave
+    if (p.reverse_walk) t = p.T - 1 - t;
     double *wl = wls[wave];
     int *wp = wps[wave];
     const int4 td = p.tiles[t];
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 __global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *__restrict__ partial)
 {
     __shared__ double red[BLOCK / 64][27];
-    const int c = blockIdx.x;
+    const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
