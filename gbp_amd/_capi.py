@@ -19,6 +19,10 @@ FLAG_DEVICE_INPUT = 2
 CAM_PARTIAL_DOUBLES = 27
 COMM_ID_BYTES = 128
 XCH_ALWAYS = 1
+PEER_HANDLE_BYTES = 64
+PEER_SAME_PROCESS = 1
+PEER_RENDEZVOUS = 2
+PEER_MAX_RANKS = 16
 EXCHANGE_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint64, ct.c_void_p)
 
 
@@ -90,6 +94,8 @@ SIGNATURES = {
     'gbp_ba_comm_init_rccl': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_char_p]),
     'gbp_ba_set_exchange': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
     'gbp_ba_comm_destroy': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_peer_export': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_void_p, ct.c_int32]),
+    'gbp_ba_peer_connect': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_void_p, ct.c_int32]),
     'gbp_ba_iterate_sharded': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
     'gbp_ba_update_beliefs_sharded': (ct.c_int, [ct.c_void_p]),
     'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),

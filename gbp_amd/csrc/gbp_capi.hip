@@ -113,6 +113,15 @@ struct gbp_ba {
     int xch_rank = 0, xch_ranks = 1, xch_flags = 0;
     double *d_send = nullptr, *d_recv = nullptr; // C*27 and n_ranks*C*27
     ncclComm_t comm = nullptr;
+    // peer-store exchange (gbp_ba_peer_export / gbp_ba_peer_connect): this rank's mailbox and the peers' mapped ones
+    struct Peer {
+        void *mailbox = nullptr; bool finegrained = false;
+        int n_ranks = 0, rank = 0; bool connected = false;
+        void *base[MAX_PEERS] = {}; bool opened[MAX_PEERS] = {};
+        unsigned long long seq = 0;
+        int *d_ctl = nullptr;                    // {arrived, err}
+        long long timeout_ticks = 0;
+    } peer;
     hipStream_t side_stream = nullptr;           // beliefs of over-sized landmarks run beside the exchange
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -260,11 +269,13 @@ static int launch_cam_partial(gbp_ba *h, double *partial)
     return GBP_OK;
 }
 
-static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, size_t stride)
+static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, size_t stride, const PeerWait *wait = nullptr)
 {
     if (!h->p.C) return GBP_OK;
+    PeerWait w{};
+    if (wait) w = *wait;
     hipLaunchKernelGGL(k_cam_finish, dim3((h->p.C + FINISH_BLOCK / 64 - 1) / (FINISH_BLOCK / 64)), dim3(FINISH_BLOCK), 0, h->stream, h->p, gathered,
-                       n_parts, stride);
+                       n_parts, stride, w);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }
@@ -290,10 +301,19 @@ static int launch_big_lmk_beliefs(gbp_ba *h, hipStream_t stream)
     return GBP_OK;
 }
 
+// general sweep / update_all_beliefs under the peer-store exchange: the finished partial sums go into every rank's mailbox
+static int launch_peer_push(gbp_ba *h, const double *partial, const PeerOut &peer)
+{
+    const int n = h->p.C * 27;
+    hipLaunchKernelGGL(k_peer_push, dim3(std::max(1, grid_for((size_t)n))), dim3(BLOCK), 0, h->stream, partial, n, peer);
+    HIPCHK(hipGetLastError());
+    return GBP_OK;
+}
+
 // defer_big: leave the beliefs of the over-sized landmarks (k_lmk_belief_list) to the caller, who runs them beside the
 // camera exchange (launch_big_lmk_beliefs)
 static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish = 0,
-                       bool *finished = nullptr, bool defer_big = false)
+                       bool *finished = nullptr, bool defer_big = false, const PeerOut *peer = nullptr)
 {
     if (finished) *finished = false;
     if (with_messages) {
@@ -318,7 +338,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         static const bool no_rev = getenv("GBP_NO_REVERSE") != nullptr;
         const int reverse = no_rev ? 0 : (int)(h->walk_parity & 1u);
         h->walk_parity ^= 1u;
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse);
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse, peer);
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (finished) *finished = finish != 0;
         return GBP_OK;
@@ -334,10 +354,12 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
         if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial);
         HIPCHK(hipGetLastError());
+        if (peer) CHK(launch_peer_push(h, partial, *peer));
         return GBP_OK;
     }
     CHK(launch_lmk_beliefs(h));                 // update_all_beliefs: from the stored messages
     CHK(launch_cam_partial(h, partial));
+    if (peer) CHK(launch_peer_push(h, partial, *peer));
     return GBP_OK;
 }
 
@@ -394,6 +416,30 @@ int rccl_exchange(void *ctx, const double *send_dev, double *recv_dev, uint64_t 
 }
 }  // namespace
 
+// mailbox geometry: data [2][n_ranks][C27] doubles, then arrival words [2][n_ranks][PEER_FLAG_STRIDE]
+static inline size_t peer_c27(const gbp_ba *h) { return (size_t)std::max(h->p.C, 1) * 27; }
+static inline size_t peer_flag_offset(const gbp_ba *h, int n) { return ((2 * (size_t)n * peer_c27(h) * sizeof(double) + 127) / 128) * 128; }
+static inline size_t peer_bytes(const gbp_ba *h, int n) { return peer_flag_offset(h, n) + 2 * (size_t)n * PEER_FLAG_STRIDE * sizeof(unsigned long long); }
+static inline double *peer_data(const gbp_ba *h, void *base, int n, int half, int src)
+{
+    return static_cast<double *>(base) + ((size_t)half * n + src) * peer_c27(h);
+}
+static inline unsigned long long *peer_flag(const gbp_ba *h, void *base, int n, int half, int src)
+{
+    return reinterpret_cast<unsigned long long *>(static_cast<char *>(base) + peer_flag_offset(h, n)) + ((size_t)half * n + src) * PEER_FLAG_STRIDE;
+}
+
+static void peer_release(gbp_ba *h)
+{
+    gbp_ba::Peer &pe = h->peer;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int r = 0; r < MAX_PEERS; ++r) {
+        if (pe.opened[r] && pe.base[r]) (void)hipIpcCloseMemHandle(pe.base[r]);
+        pe.opened[r] = false; pe.base[r] = nullptr;
+    }
+    pe.connected = false;
+}
+
 static void shard_comm_release(gbp_ba *h)
 {
     if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); (void)g_rccl.CommDestroy(h->comm); }
@@ -423,6 +469,9 @@ void gbp_ba_destroy(gbp_ba_t *h)
     for (int i = 0; i < 2; ++i) { if (h->h_mu[i]) (void)hipHostFree(h->h_mu[i]); if (h->ev_landed[i]) (void)hipEventDestroy(h->ev_landed[i]); }
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     shard_comm_release(h);
+    peer_release(h);
+    if (h->peer.mailbox) (void)hipFree(h->peer.mailbox);
+    if (h->peer.d_ctl) (void)hipFree(h->peer.d_ctl);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -714,6 +763,14 @@ int gbp_ba_sync(gbp_ba_t *h)
 {
     ENTER(h);
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->peer.connected && h->peer.d_ctl) {              // a finish kernel gave up waiting for a peer's partial sums?
+        int err = 0;
+        HIPCHK(hipMemcpy(&err, h->peer.d_ctl + 1, sizeof(int), hipMemcpyDeviceToHost));
+        if (err) {
+            HIPCHK(hipMemset(h->peer.d_ctl + 1, 0, sizeof(int)));
+            return fail(GBP_ESTATE, "peer-store exchange timed out: a rank's camera partial sums did not arrive (the camera beliefs since then are invalid)");
+        }
+    }
     return GBP_OK;
 }
 
@@ -905,14 +962,111 @@ int gbp_ba_comm_destroy(gbp_ba_t *h)
 {
     ENTER(h);
     shard_comm_release(h);
+    peer_release(h);
+    return GBP_OK;
+}
+
+int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t flags)
+{
+    ENTER(h);
+    if (!handle64 || n_ranks < 1 || n_ranks > MAX_PEERS) return fail(GBP_EINVAL, "peer exchange: 1..%d ranks", MAX_PEERS);
+    gbp_ba::Peer &pe = h->peer;
+    peer_release(h);
+    if (pe.mailbox) { HIPCHK(hipFree(pe.mailbox)); pe.mailbox = nullptr; }
+    const size_t bytes = peer_bytes(h, n_ranks);
+    // fine-grained (uncached across devices) when the runtime grants it: peers store into it over xGMI while this rank polls it
+    pe.finegrained = hipExtMallocWithFlags(&pe.mailbox, bytes, hipDeviceMallocFinegrained) == hipSuccess;
+    if (!pe.finegrained) { (void)hipGetLastError(); HIPCHK(hipMalloc(&pe.mailbox, bytes)); }
+    HIPCHK(hipMemsetAsync(pe.mailbox, 0, bytes, h->stream));
+    if (!pe.d_ctl) HIPCHK(hipMalloc(reinterpret_cast<void **>(&pe.d_ctl), 2 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(pe.d_ctl, 0, 2 * sizeof(int), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    pe.n_ranks = n_ranks; pe.seq = 0;
+    std::memset(handle64, 0, GBP_PEER_HANDLE_BYTES);
+    if (flags & GBP_PEER_SAME_PROCESS) {
+        std::memcpy(handle64, &pe.mailbox, sizeof(void *));
+    } else {
+        hipIpcMemHandle_t ipc;
+        static_assert(sizeof(ipc) <= GBP_PEER_HANDLE_BYTES, "hipIpcMemHandle_t size");
+        HIPCHK(hipIpcGetMemHandle(&ipc, pe.mailbox));
+        std::memcpy(handle64, &ipc, sizeof ipc);
+    }
+    return GBP_OK;
+}
+
+int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *handles, int32_t flags)
+{
+    ENTER(h);
+    gbp_ba::Peer &pe = h->peer;
+    if (!handles || !pe.mailbox || n_ranks != pe.n_ranks || rank < 0 || rank >= n_ranks)
+        return fail(GBP_EINVAL, "peer exchange: connect needs the %d handles of gbp_ba_peer_export (rank %d of %d)", pe.n_ranks, rank, n_ranks);
+    peer_release(h);
+    shard_comm_release(h);
+    const char *hs = static_cast<const char *>(handles);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) { pe.base[r] = pe.mailbox; continue; }
+        if (flags & GBP_PEER_SAME_PROCESS) {
+            std::memcpy(&pe.base[r], hs + (size_t)r * GBP_PEER_HANDLE_BYTES, sizeof(void *));
+        } else {
+            hipIpcMemHandle_t ipc;
+            std::memcpy(&ipc, hs + (size_t)r * GBP_PEER_HANDLE_BYTES, sizeof ipc);
+            HIPCHK(hipIpcOpenMemHandle(&pe.base[r], ipc, hipIpcMemLazyEnablePeerAccess));
+            pe.opened[r] = true;
+        }
+        if (!pe.base[r]) return fail(GBP_EINVAL, "peer exchange: rank %d's mailbox handle is empty", r);
+    }
+    CHK(shard_buffers(h, 1));                                // d_send: the partial sums of the general sweep on their way to the mailboxes
+    pe.rank = rank;
+    double ms = 20000.0;                                     // how long a finish kernel waits for a peer before it gives up
+    if (const char *e = getenv("GBP_PEER_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
+    pe.timeout_ticks = (long long)(ms * 1e5);                // wall_clock64: 100 MHz
+    if (!(flags & GBP_PEER_RENDEZVOUS)) { h->xch_fn = nullptr; h->xch_ctx = nullptr; }
+    h->xch_rank = rank; h->xch_ranks = n_ranks;
+    pe.connected = true;
     return GBP_OK;
 }
 
 // one sharded sweep (or belief update) on the handle's stream: local kernels -> camera partial sums -> exchange -> rank-ordered
 // sum + prior + 6x6 solve.  With one rank and no GBP_XCH_ALWAYS nothing is exchanged and the camera beliefs are finished by
 // the reduce launch itself, exactly like gbp_ba_iterate.
+// one sharded sweep under the peer-store exchange: no collective, no host synchronisation -- the reduce kernel stores this rank's
+// partial sums into every rank's mailbox and raises the arrival words, the finish kernel waits for all of them
+static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int local_relin)
+{
+    gbp_ba::Peer &pe = h->peer;
+    const int n = pe.n_ranks, half = (int)(++pe.seq & 1ull);
+    PeerOut po{};
+    po.n = n; po.seq = pe.seq; po.arrived = pe.d_ctl;
+    for (int r = 0; r < n; ++r) {
+        po.dst[r] = peer_data(h, pe.base[r], n, half, pe.rank);
+        po.flag[r] = peer_flag(h, pe.base[r], n, half, pe.rank);
+    }
+    const bool big = with_messages && !h->big_lmks.empty();
+    CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, nullptr, big, &po));
+    if (big) {
+        if (!h->side_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        CHK(launch_big_lmk_beliefs(h, h->side_stream));
+        HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
+    }
+    if (h->xch_fn) {                                         // optional rendezvous hook (logical ranks on ONE device: tests)
+        int rc = h->xch_fn(h->xch_ctx, nullptr, nullptr, 0, h->stream);
+        if (rc != GBP_OK) return rc < 0 ? rc : fail(GBP_EHIP, "the rendezvous function returned %d", rc);
+    }
+    PeerWait w{peer_flag(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1};
+    CHK(launch_cam_finish(h, peer_data(h, pe.mailbox, n, half, 0), n, peer_c27(h), &w));
+    if (big) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    return GBP_OK;
+}
+
 static int sharded_step(gbp_ba *h, int with_messages, int robustify, int local_relin)
 {
+    if (h->peer.connected) return sharded_step_peer(h, with_messages, robustify, local_relin);
     const bool exchange = h->xch_ranks > 1 || ((h->xch_flags & GBP_XCH_ALWAYS) && h->xch_fn);
     if (!exchange) {
         bool finished = false;
@@ -945,7 +1099,7 @@ int gbp_ba_iterate_sharded(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int3
     ENTER(h);
     h->resid_ok = false;
     if (n_iters < 0) return fail(GBP_EINVAL, "n_iters < 0");
-    if (!h->d_send) return fail(GBP_ESTATE, "no exchange set (gbp_ba_comm_init_rccl / gbp_ba_set_exchange)");
+    if (!h->d_send) return fail(GBP_ESTATE, "no exchange set (gbp_ba_comm_init_rccl / gbp_ba_set_exchange / gbp_ba_peer_connect)");
     for (int it = 0; it < n_iters; ++it) CHK(sharded_step(h, 1, robustify, local_relin));
     h->has_beliefs = true;
     return GBP_OK;

@@ -346,7 +346,7 @@ constexpr int RED_THREADS = 1024;      // the copy into LDS is the latency of th
                                        // (55 KB at 256 workgroups) in flight at once, four 16-byte loads per thread (256 threads with a
                                        // rolled loop: 8.1 us at C = 500 and 9.0 us for the 63 cameras of fr1desk)
 __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
-                                                                 double *__restrict__ partial, int finish)
+                                                                 double *__restrict__ partial, int finish, PeerOut peer)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][27] | red[RED_PARTS][27] | tot[27]
     const int c = blockIdx.x, n = n_blocks * TROW, tid = threadIdx.x;
@@ -379,8 +379,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
 #pragma unroll
         for (int q = 1; q < RED_PARTS; ++q) s += red[q * 27 + tid];
         partial[(size_t)c * 27 + tid] = s;
+        for (int r = 0; r < peer.n; ++r) peer_store(peer.dst[r] + (size_t)c * 27 + tid, s);      // sharded, peer-store exchange: straight into every rank's mailbox
         tot[tid] = s + p.cprior[(size_t)c * 27 + tid];
     }
+    if (peer.n) peer_arrive(peer);
     if (!finish) return;
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
@@ -502,7 +504,8 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 
 // returns 0 or a hipError_t value
 inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int local_relin, double *partial, hipStream_t stream,
-                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false, int reverse = 0)
+                        int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false, int reverse = 0,
+                        const PeerOut *peer = nullptr)
 {
     pl.args.reverse = reverse;
     Params p = p0;
@@ -524,7 +527,9 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     }
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
     const size_t red_shmem = sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27);
-    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish);
+    PeerOut po{};
+    if (peer) po = *peer;
+    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po);
     return (int)hipGetLastError();
 }
 

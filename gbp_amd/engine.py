@@ -190,6 +190,21 @@ class BAEngine:
         check(self._lib.gbp_ba_set_exchange(self._h, ct.cast(self._xch_cb, ct.c_void_p), None, int(rank), int(n_ranks),
                                             _capi.XCH_ALWAYS if always_exchange else 0))
 
+    def peer_export(self, n_ranks, same_process=False):
+        """This rank's mailbox for the peer-store exchange (gbp_ba_peer_export): 64 bytes to hand to every other rank."""
+        buf = ct.create_string_buffer(_capi.PEER_HANDLE_BYTES)
+        check(self._lib.gbp_ba_peer_export(self._h, int(n_ranks), buf, _capi.PEER_SAME_PROCESS if same_process else 0))
+        return buf.raw
+
+    def peer_connect(self, rank, handles, same_process=False, rendezvous=False):
+        """handles: the peer_export() bytes of all ranks in rank order.  From here on iterate_sharded / update_beliefs_sharded
+        exchange the camera partial sums by direct stores into the ranks' mailboxes (no collective call)."""
+        blob = b''.join(bytes(x) for x in handles)
+        if len(blob) != _capi.PEER_HANDLE_BYTES * len(handles):
+            raise ValueError("every handle must be the 64 bytes of peer_export()")
+        flags = (_capi.PEER_SAME_PROCESS if same_process else 0) | (_capi.PEER_RENDEZVOUS if rendezvous else 0)
+        check(self._lib.gbp_ba_peer_connect(self._h, int(rank), len(handles), ct.c_char_p(blob), flags))
+
     def comm_destroy(self):
         check(self._lib.gbp_ba_comm_destroy(self._h))
 

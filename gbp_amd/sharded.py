@@ -62,18 +62,44 @@ class _HipShard:
         self.stream = torch.cuda.Stream(self.device)
         self.engine.set_stream(self.stream.cuda_stream)
 
-    def init_comm(self, dist, always_exchange=False):
-        """The exchange of the in-library loop.  Real process groups: the library's own RCCL communicator (rank 0 makes the
-        id, the process group carries it to the others).  A `dist` object that brings its own `device_exchange(rank, send_ptr,
-        recv_ptr, count, stream_ptr)` (the thread-rank test double; an MPI build would do the same) is plugged in as the
-        exchange function instead."""
+    def init_comm(self, dist, always_exchange=False, exchange='auto'):
+        """The exchange of the in-library loop; returns its name.
+          'rccl'     the library's own RCCL communicator (rank 0 makes the id, the process group carries it to the others):
+                     one ncclAllGather per sweep on the engine's stream;
+          'peer'     no collective: every rank's reduce kernel stores its partial sums straight into the mailboxes of all
+                     ranks (xGMI peer stores), the finish kernel waits for the arrival words (gbp_ba_peer_connect);
+          'callback' a `dist` object that brings its own `device_exchange(rank, send_ptr, recv_ptr, count, stream_ptr)` (the
+                     thread-rank test double; an MPI build would do the same) is plugged in as the exchange function.
+        'auto' = 'callback' when the dist object has one, else 'rccl'."""
         rank, world = dist.get_rank(), dist.get_world_size()
-        if hasattr(dist, 'device_exchange'):
+        threads = hasattr(dist, 'device_exchange')           # ranks are threads of ONE process on one device
+        if exchange == 'auto':
+            exchange = 'callback' if threads else 'rccl'
+        if exchange == 'callback':
             self.engine.set_exchange(lambda s, r, n, st: dist.device_exchange(rank, s, r, n, st), rank, world, always_exchange)
-            return
-        ids = [self.engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        self.engine.comm_init_rccl(ids[0], rank, world, always_exchange)
+        elif exchange == 'peer':
+            if threads:                                      # logical ranks must not spin on each other: rendezvous hook between
+                self.engine.set_exchange(lambda s, r, n, st: dist.device_exchange(rank, s, r, n, st), rank, world, False)
+            mine = self.engine.peer_export(world, same_process=threads)
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            self.engine.peer_connect(rank, handles, same_process=threads, rendezvous=threads)
+            dist.barrier()                                   # nobody stores into a mailbox its owner has not set up yet
+        elif exchange == 'rccl':
+            # rank 0 may fail to make the id (librccl not loadable): everybody must still leave the broadcast
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids = [self.engine.comm_unique_id()]
+                except Exception as e:                       # noqa: BLE001 -- carried to every rank below
+                    ids = [f"error: {e}"]
+            dist.broadcast_object_list(ids, src=0)
+            if not isinstance(ids[0], (bytes, bytearray)):
+                raise RuntimeError(f"rank 0 could not create the RCCL id ({ids[0]})")
+            self.engine.comm_init_rccl(ids[0], rank, world, always_exchange)
+        else:
+            raise ValueError(f"unknown exchange {exchange!r} ('auto', 'rccl', 'peer', 'callback')")
+        return exchange
 
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
@@ -98,7 +124,7 @@ class ShardedBA:
     """BAFactorGraph surface (gbp_ba.py:12-69) over `world` ranks; every rank calls every method."""
 
     def __init__(self, problem: BAProblem, device=0, fused=True, engine_factory=None, dist=None, library_loop=True,
-                 always_exchange=False, **cfg):
+                 always_exchange=False, exchange='auto', **cfg):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -116,11 +142,12 @@ class ShardedBA:
         self._partial = self.shard.new_buffer(n)
         self._gathered = self.shard.new_buffer(n * self.world)
         self.library_loop = False
+        self.exchange = 'python'                            # how the camera partial sums travel: python | rccl | peer | callback
         if hasattr(self.shard, 'init_comm') and library_loop:
             # every rank must take the same path: agree on whether the library's communicator came up everywhere, else all
             # ranks drive the sweep from Python over the process group (slower per sweep, same results)
             try:
-                self.shard.init_comm(dist, always_exchange)
+                self.exchange = self.shard.init_comm(dist, always_exchange, exchange)
                 ok = 1
             except Exception as e:                          # noqa: BLE001 -- reported below, the job goes on
                 import sys
@@ -136,6 +163,8 @@ class ShardedBA:
                 self.library_loop = bool(t.cpu().numpy()[0] > 0.5)
                 if ok and not self.library_loop:
                     self.engine.comm_destroy()
+            if not self.library_loop:
+                self.exchange = 'python'
 
     # ---- set-up ---------------------------------------------------------------------------
     def generate_priors_var(self, weaker_factor=100.0):

@@ -151,6 +151,22 @@ int gbp_ba_comm_unique_id(void *id128, const char *rccl_path);
 int gbp_ba_comm_init_rccl(gbp_ba_t *h, const void *id128, int32_t rank, int32_t n_ranks, int32_t flags, const char *rccl_path);
 int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank, int32_t n_ranks, int32_t flags);
 int gbp_ba_comm_destroy(gbp_ba_t *h);
+/*   - gbp_ba_peer_export / gbp_ba_peer_connect: NO collective call.  Every rank owns a mailbox in its own device memory; the
+ *     kernel that finishes a rank's partial sums stores them straight into the mailbox of every rank (peer stores over xGMI
+ *     on a multi-GPU node) and raises an arrival word, the finish kernel of a rank polls the arrival words of its own
+ *     mailbox.  export allocates the mailbox for n_ranks and writes a 64-byte handle (a hipIpcMemHandle_t for other
+ *     PROCESSES; with GBP_PEER_SAME_PROCESS the raw device address, for ranks that are threads of one process); carry the
+ *     handles of all ranks, in rank order, to every rank over any side channel and pass them to connect.  All ranks must
+ *     have connected before the first sharded call (barrier on the side channel).  GBP_PEER_RENDEZVOUS keeps the function
+ *     set with gbp_ba_set_exchange as a hook called with (NULL, NULL, 0, stream) between the stores and the finish (logical
+ *     ranks on ONE device must not spin on each other).  A finish kernel gives up after GBP_PEER_TIMEOUT_MS (default
+ *     20000) and gbp_ba_sync then returns GBP_ESTATE. */
+#define GBP_PEER_HANDLE_BYTES 64
+#define GBP_PEER_SAME_PROCESS 1
+#define GBP_PEER_RENDEZVOUS 2
+#define GBP_PEER_MAX_RANKS 16
+int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t flags);
+int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *handles, int32_t flags);
 int gbp_ba_iterate_sharded(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin);   /* n x synchronous_iteration gbp.py:86-92 */
 int gbp_ba_update_beliefs_sharded(gbp_ba_t *h);                                                     /* update_all_beliefs gbp.py:56-58 */
 

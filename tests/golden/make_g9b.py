@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """Fixture G9b (optional): the FULL headline graph (500 cams x 100k landmarks x 1M factors, the build's
-generator with seed 0) through the reference itself for two sweeps; stores the 500 camera beliefs and 2000 sampled
-landmark beliefs after update_all_beliefs and after sweeps 1 and 2.
+generator with seed 0) through the reference itself for --sweeps sweeps (default 10) of the no-reset schedule bench.py
+times: iters_since_relin starts at 1 (gbp.py:249), so nobody relinearises before sweep 8 (min_linear_iters = 8), sweep 8
+relinearises every factor that moved by more than beta, sweeps 9 and 10 are the first undamped sweeps after it.  Stores the 500 camera beliefs and 2000 sampled landmark beliefs after
+update_all_beliefs and after sweeps 1, 2, 8, 9, 10, the ARE after every sweep, the number of factors with
+iters_since_relin == 0 after every sweep (ba.py:96-99) and, for 4000 sampled factors, iters_since_relin and eta_damping
+after sweeps 9 and 10.
 
 The reference's create_ba_graph scans all observations once per camera (gbp_ba.py:128-130: 5e8 Python iterations at this
 size), so the graph is assembled here with the same classes in the same order (camera-major, file order inside a camera)
 without that scan; everything else -- Factor.compute_factor, generate_priors_var, update_all_beliefs,
-synchronous_iteration -- is the reference's own code.  Takes ~15 minutes and ~6 GB.  Run from the repo root:
+synchronous_iteration -- is the reference's own code.  Takes ~45 minutes and ~6 GB.  Run from the repo root:
     python tests/golden/make_g9b.py [--reference /root/reference]
 """
 import argparse, os, sys, time
@@ -15,6 +19,8 @@ import numpy as np
 ap = argparse.ArgumentParser()
 ap.add_argument('--reference', default='/root/reference')
 ap.add_argument('--lmks', type=int, default=100_000)
+ap.add_argument('--sweeps', type=int, default=10)
+ap.add_argument('--out', default=None)
 args = ap.parse_args()
 sys.dont_write_bytecode = True
 REPO = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
@@ -65,9 +71,20 @@ def snap(tag):
     out[tag + '_are'] = graph.are()
 
 snap('it0')
-for it in (1, 2):
+fsample = np.sort(rs.choice(F, size=min(4000, F), replace=False))
+out['factor_sample'] = fsample
+are_trace, relin_trace = [out['it0_are']], []
+for it in range(1, args.sweeps + 1):
     graph.synchronous_iteration(robustify=True, local_relin=True)
-    print(f"sweep {it} done ({time.time() - t0:.0f} s)", flush=True)
-    snap(f'it{it}')
-np.savez_compressed(os.path.join(REPO, 'tests', 'golden', f'G9b_synthetic_full_{F}.npz'), **out)
+    are_trace.append(graph.are())
+    relin_trace.append(sum(1 for f in graph.factors if f.iters_since_relin == 0))      # ba.py:96-99
+    print(f"sweep {it} done ({time.time() - t0:.0f} s): ARE {are_trace[-1]:.6f}, relinearised {relin_trace[-1]}", flush=True)
+    if it in (1, 2, 8, 9, 10):
+        snap(f'it{it}')
+    if it in (9, 10):
+        out[f'it{it}_iters_since_relin'] = np.array([graph.factors[i].iters_since_relin for i in fsample], dtype=np.int32)
+        out[f'it{it}_eta_damping'] = np.array([graph.factors[i].eta_damping for i in fsample])
+out['are_trace'] = np.array(are_trace)
+out['relin_trace'] = np.array(relin_trace, dtype=np.int64)
+np.savez_compressed(args.out or os.path.join(REPO, 'tests', 'golden', f'G9b_synthetic_full_{F}.npz'), **out)
 print("saved", {k: np.shape(v) for k, v in out.items()})

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""One-GPU sweep time of the shards a 2 / 4 / 8-rank run gives every rank (500k / 250k / 125k factors of the headline graph's
+family): the plain engine (gbp_ba_iterate: fused sweep + reduce-and-finish), the general sweep, and the in-library sharded
+loop with the peer-store exchange at one rank (reduce -> mailbox -> finish that polls the arrival word: everything a rank
+does per sweep except waiting for the others).  Writes gpurun_out/shard_probe.json (copied to profiles/ by hand).
+
+    python tools/shard_probe.py [--sizes 50000 25000 12500] [--reps 400]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from gbp_amd.synthetic import make_synthetic
+from gbp_amd.engine import BAEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--sizes', type=int, nargs='*', default=[50_000, 25_000, 12_500])
+ap.add_argument('--reps', type=int, default=400)
+ap.add_argument('--out', default='gpurun_out/shard_probe.json')
+ap.add_argument('--modes', nargs='*', default=['engine', 'general', 'peer1'])
+args = ap.parse_args()
+rows = []
+for n_l in args.sizes:
+    p = make_synthetic(n_cams=500, n_lmks=n_l, obs_per_lmk=10, seed=0)
+    for mode in args.modes:
+        e = BAEngine.from_problem(p, fused=(mode != 'general'))
+        if mode == 'peer1':
+            e.peer_connect(0, [e.peer_export(1)])
+            it, upd = e.iterate_sharded, e.update_beliefs_sharded
+        else:
+            it, upd = e.iterate, e.update_all_beliefs
+        e.generate_priors_var(50.0); upd(); e.sync()
+        e.snapshot_state()
+        best = []
+        for rep in range(3):
+            e.restore_snapshot(); it(7); e.sync()            # steady sweeps only: nobody relinearises before sweep 9 ...
+            ts = []
+            for _ in range(args.reps // 8):                   # ... so time one sweep at a time, eight per restore
+                e.restore_snapshot(); it(1); e.sync()
+                t0 = time.perf_counter(); it(7); e.sync(); ts.append((time.perf_counter() - t0) / 7)
+            best.append(sorted(ts)[len(ts) // 2])
+        us = min(best) * 1e6
+        info = e.info()
+        rows.append(dict(n_lmks=n_l, n_factors=p.n_factors, mode=mode, us_per_sweep=us, n_blocks=info['n_blocks'], n_tiles=info['n_tiles']))
+        print(f"F={p.n_factors:8d} {mode:8s}: {us:7.1f} us/sweep  (workgroups {info['n_blocks']}, tiles {info['n_tiles']})", flush=True)
+        e.close()
+os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
+json.dump(rows, open(args.out, 'w'), indent=1)
