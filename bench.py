@@ -12,15 +12,18 @@ torch.distributed.run on 127.0.0.1); started under torchrun it uses the ranks it
 Timing protocol.  Every batch starts from the same state -- the graph right after generate_priors_var +
 update_all_beliefs, restored from a device-resident checkpoint -- runs W untimed sweeps and then EXACTLY K timed sweeps bracketed by a
 barrier + device synchronisation on both sides (max over ranks).  Batches are repeated until >= 0.5 s have been timed;
-`value` = K / median batch time, the minimum is reported beside it.  HIP events bracket every launch of the dominant
-kernel in one extra, untimed replay of the same batch, and the device counts the factors that relinearise in each sweep:
-steady sweeps (fewer than 1 factor in 1000 relinearises: the case SURVEY 8d's byte count describes) and relinearising
-sweeps are reported separately.
+`value` = K / median batch time, the minimum is reported beside it.  One extra, untimed replay of the same batch is
+instrumented: every kernel of every sweep stamps the device's constant-rate clock (first workgroup in, last workgroup out --
+what rocprofv3 reports as the kernel's duration), HIP events bracket every 7th launch of the dominant kernel as a cross-check
+(an event pair also times the dispatch behind its barrier packet), and the device counts the factors that relinearise in each
+sweep: steady sweeps (fewer than 1 factor in 1000 relinearises: the case SURVEY 8d's byte count describes) and relinearising
+sweeps are reported separately.  N > 1 also prints per-rank device times (sweep / reduce / exchange / finish) and the rank
+count the exchange itself reports.
 
 Roofline bookkeeping.  `roofline.achieved` = the bytes the engine's data layout MUST move per launch of the dominant
 kernel (F (21 read + 10 written doubles + 12 B of indices / state) + L (24 + 12 doubles) + one
 camera table per workgroup) / the mean steady launch time; `frac` = achieved / 8 TB/s, never above 1.  `traffic` = HBM
-bytes per launch measured by the PMC passes committed under profiles/.  The survey's 1072 B/factor model of a dense
+bytes per launch from the rocprofv3 PMC passes committed under profiles/ (not measured by this run).  The survey's 1072 B/factor model of a dense
 two-pass implementation is kept only as `survey_equivalent_*`: this engine does that work in fewer bytes.
 """
 import argparse
@@ -39,6 +42,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 MIN_TIMED_S = 0.5
+EVENT_EVERY = 7               # HIP events bracket every 7th launch of the dominant kernel in the instrumented replay (cross-check)
 MAX_BATCHES = 2000          # (a 20-step batch of a 15 us sweep is 0.3 ms: the cap only bounds degenerate cases)
 
 
@@ -68,9 +72,11 @@ def host_cores():
     return n
 
 
-def cpu_baseline(problem, budget_s=20.0):
+def cpu_baseline(problem, budget_s=20.0, engine=None):
     """Time the CPU oracle (oracle/gbp_oracle.c, a port of the reference's algorithm) on the same workload,
-    bounded to ~budget_s of wall time: a few whole sweeps of the same graph at 1 thread and at several OpenMP widths."""
+    bounded to ~budget_s of wall time: a few whole sweeps of the same graph at 1 thread and at several OpenMP widths.
+    With `engine` (the measured graph, snapshot of its initial state taken): the engine replays as many sweeps as the oracle
+    has done by then and the two average reprojection errors must agree to 1e-8 -- the checker's only other use here."""
     from oracle import oracle
     o = oracle.OracleBA.from_problem(problem, threads=1)
     o.generate_priors_var(50.0)
@@ -79,7 +85,7 @@ def cpu_baseline(problem, budget_s=20.0):
     o.iterate(1)                                              # also the warm-up sweep
     dt1 = time.perf_counter() - t0
     best = (dt1, 1, 1)
-    spent = dt1
+    spent, sweeps = dt1, 1
     for threads in sorted({min(host_cores(), t) for t in (8, 32, 64, host_cores())}):
         if threads == 1 or spent > budget_s:
             continue
@@ -90,12 +96,24 @@ def cpu_baseline(problem, budget_s=20.0):
         o.iterate(n)
         dt = (time.perf_counter() - t0) / n
         spent += dt * (n + 1)
+        sweeps += n + 1
         if dt < best[0]:
             best = (dt, threads, n)
-    return {"value": 1.0 / best[0], "unit": "iter/s", "cores": best[1], "kind": "port",
-            "sample": f"{best[2]} whole sweeps of the same {problem.n_factors}-factor graph (after warm-up), C oracle with "
-                      f"OpenMP over factors/variables, best of several thread counts on {host_cores()} usable cores",
-            "value_1thread": 1.0 / dt1, "us_per_factor_iter_1thread": dt1 / problem.n_factors * 1e6}
+    out = {"value": 1.0 / best[0], "unit": "iter/s", "cores": best[1], "kind": "port",
+           "sample": f"{best[2]} whole sweeps of the same {problem.n_factors}-factor graph (after warm-up), C oracle with "
+                     f"OpenMP over factors/variables, best of several thread counts on {host_cores()} usable cores",
+           "value_1thread": 1.0 / dt1, "us_per_factor_iter_1thread": dt1 / problem.n_factors * 1e6}
+    if engine is not None:
+        while sweeps < 10 and spent < 2 * budget_s:          # through the first relinearising sweep (sweep 8) when the budget allows
+            t0 = time.perf_counter(); o.iterate(1); spent += time.perf_counter() - t0; sweeps += 1
+        engine.restore_snapshot()
+        engine.iterate(sweeps)
+        a_e, a_o = engine.are(), o.are()
+        gap = abs(a_e - a_o) / abs(a_o)
+        out["are_check"] = {"sweeps": sweeps, "engine": a_e, "oracle": a_o, "rel_gap": gap, "ok": bool(gap < 1e-8)}
+        if gap >= 1e-8:
+            print(f"[bench] WARNING: ARE after {sweeps} sweeps: engine {a_e!r} vs oracle {a_o!r} (rel {gap:.2e})", file=sys.stderr)
+    return out
 
 
 def cpu_baseline_numpy(problem, budget_s=15.0):
@@ -130,6 +148,57 @@ def measured_traffic():
         return None, None
 
 
+def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_graph):
+    """N > 1: the same job once more with the peer-store exchange (gbp_ba_peer_connect: the reduce kernels store the camera partial
+    sums straight into every rank's mailbox over xGMI, the finish kernels poll arrival words; no collective call).  Every step
+    is agreed on by all ranks; any failure (IPC handles, a time-out in the two-sweep probe) just returns None.  Returns the
+    measure() dict + `matches_rccl`: camera beliefs after two sweeps from the same start are bitwise those of the RCCL path."""
+    from gbp_amd.sharded import ShardedBA
+    os.environ.setdefault('GBP_PEER_TIMEOUT_MS', '3000')
+
+    def agreed(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    g = None
+    try:
+        g = ShardedBA(problem, device=local_rank, fused=not args.no_fused, exchange='peer')
+        ok = g.exchange == 'peer'
+    except Exception as e:                                     # noqa: BLE001
+        print(f"[bench] peer-store exchange unavailable: {e}", file=sys.stderr)
+        ok = False
+    if not agreed(ok):
+        if g is not None:
+            g.close()
+        return None
+    try:
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+        g.iterate(2)
+        g.sync()                                               # reports a finish kernel that gave up waiting
+        ok = True
+    except Exception as e:                                     # noqa: BLE001
+        print(f"[bench] peer-store exchange probe failed: {e}", file=sys.stderr)
+        ok = False
+    if not agreed(ok):
+        g.close()
+        return None
+    rccl_graph.restore_snapshot()
+    rccl_graph.iterate(2)
+    a, b = rccl_graph.camera_beliefs(), g.camera_beliefs()
+    match = agreed(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+    try:
+        m = measure(g, min_timed_s=MIN_TIMED_S / 2)
+        m['matches_rccl'] = match
+    except Exception as e:                                     # noqa: BLE001
+        print(f"[bench] peer-store exchange run failed: {e}", file=sys.stderr)
+        m = None
+    ok = agreed(m is not None)
+    g.close()
+    return m if ok else None
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -162,6 +231,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-batch', action='store_true', help='one timed batch only (profiling runs)')
     ap.add_argument('--sharded', action='store_true', help='take the N > 1 code path (process group, ShardedBA, RCCL exchange forced) even with one rank')
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'rccl', 'peer'],
+                    help='N > 1: how the camera partial sums travel.  rccl = one ncclAllGather per sweep on the library\'s communicator; peer = '
+                         'direct stores into the ranks\' mailboxes, no collective; auto = measure rccl, then peer, report the faster as `value` '
+                         'and the other beside it')
     ap.add_argument('--python-loop', action='store_true', help='N > 1: drive the sweeps from Python (shard_begin / all_gather / shard_end)')
     ap.add_argument('--dump-sweeps', default=None, help='write the per-sweep kernel times (ms) and relinearisation counts of the instrumented replay to this .npz')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend of the side channel (tests: gloo)')
@@ -217,7 +290,7 @@ def main():
                 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
             dist.init_process_group(args.backend, device_id=torch.device('cuda', local_rank))
             graph = ShardedBA(problem, device=local_rank, fused=not args.no_fused, library_loop=not args.python_loop,
-                              always_exchange=args.sharded)
+                              always_exchange=args.sharded, exchange='peer' if args.exchange == 'peer' else 'rccl')
     else:
         from gbp_amd.engine import BAEngine
         graph = BAEngine.from_problem(problem, device=local_rank, fused=not args.no_fused)
@@ -228,51 +301,116 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
-    graph.generate_priors_var(50.0)
-    graph.update_all_beliefs()
-    graph.sync()
-    if not dry:
-        graph.snapshot_state()                                 # device-resident: restoring it leaves no idle gap before the sweeps
-
-    def batch(timing=False):
-        """Restore the initial state, W untimed sweeps, then K sweeps between two fences.  Returns wall seconds (max over ranks)."""
+    def measure(graph, min_timed_s=MIN_TIMED_S):
+        """The timing protocol on one graph object: returns batch times + the kernel-level picture of one instrumented replay."""
+        graph.generate_priors_var(50.0)
+        graph.update_all_beliefs()
+        graph.sync()
         if not dry:
-            graph.restore_snapshot()
-        graph.iterate(args.warmup)
-        graph.sync()
-        if timing:
-            graph.set_kernel_timing(1)
-        fence()
-        t0 = time.perf_counter()
-        graph.iterate(args.steps)
-        graph.sync()
-        fence()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else 'cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+            graph.snapshot_state()                             # device-resident: restoring it leaves no idle gap before the sweeps
 
-    batch()                                                   # untimed: page in code, caches, clocks
-    times = [batch()]
-    while not args.single_batch and sum(times) < MIN_TIMED_S and len(times) < MAX_BATCHES:
-        times.append(batch())
-    times = np.array(times)
+        def batch(timing=0):
+            """Restore the initial state, W untimed sweeps, then K sweeps between two fences.  Returns wall seconds (max over ranks)."""
+            if not dry:
+                graph.restore_snapshot()
+            graph.iterate(args.warmup)
+            graph.sync()
+            if timing:
+                graph.set_kernel_timing(timing)
+            fence()
+            t0 = time.perf_counter()
+            graph.iterate(args.steps)
+            graph.sync()
+            fence()
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else 'cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
+
+        batch()                                               # untimed: page in code, caches, clocks
+        times = [batch()]
+        while not args.single_batch and sum(times) < min_timed_s and len(times) < MAX_BATCHES:
+            times.append(batch())
+        m = dict(times=np.array(times), ev_ms=np.zeros(0), clk=np.zeros((0, 6)), relin=np.zeros(0, np.int64), k_name='')
+        if not dry:
+            # One more, untimed replay of the same batch, instrumented: every kernel of every sweep stamps the device's
+            # constant-rate clock (first workgroup in, last workgroup out), and HIP events bracket every EVENT_EVERY-th launch of
+            # the dominant kernel as a cross-check (an event pair around a launch also times the dispatch behind the event's
+            # barrier packet and serialises the stream, so it is neither put around every launch nor used for the roofline).
+            batch(timing=EVENT_EVERY)
+            m['clk'] = graph.sweep_clocks()[:args.steps]
+            m['ev_ms'] = graph.kernel_times()
+            _, _, m['k_name'] = graph.kernel_timing()
+            graph.set_kernel_timing(0)
+            if args.steps <= 512:
+                m['relin'] = np.asarray(graph.relin_counts(args.steps), dtype=np.int64)
+        m['are'] = graph.are()
+        return m
+
+    def kernel_picture(m, F_total):
+        """Per-sweep device times (ms) from the clock stamps, split into steady and relinearising sweeps."""
+        clk, relin = m['clk'], m['relin']
+        n = clk.shape[0]
+        pic = dict(n=n)
+        if not n:
+            return pic
+        # START stamps tile the timeline like rocprofv3's kernel durations do: a kernel's interval runs from its first workgroup to the
+        # first workgroup of the next kernel (its own drain and the next dispatch included).  `busy` is first workgroup in -> last out.
+        step = np.diff(clk[:, 0]) * 1e-3                          # sweep start to next sweep start
+        nxt = np.append(clk[1:, 0], np.nan)                      # start of the next sweep
+        sweep = (clk[:, 2] - clk[:, 0]) * 1e-3
+        busy = (clk[:, 1] - clk[:, 0]) * 1e-3
+        sharded_step = np.isfinite(clk[:, 4])
+        reduce_ = (np.where(sharded_step, clk[:, 4], nxt) - clk[:, 2]) * 1e-3     # (with an exchange in between: reduce + exchange, see xch)
+        finish = (nxt - clk[:, 4]) * 1e-3
+        xch = np.full(n, np.nan)                                  # not separable from the reduce by start stamps alone: reported together
+        steady = relin * 1000 < F_total if relin.size == n else np.ones(n, bool)   # fewer than 1 factor in 1000 relinearises
+        if not steady.any():
+            steady = np.ones(n, bool)
+        ok = steady & np.isfinite(sweep)
+        pic.update(sweep=sweep, busy=busy, reduce=reduce_, finish=finish, xch=xch, step=step, steady=steady, ok=ok,
+                   ev_idx=np.arange(0, n, EVENT_EVERY)[:m['ev_ms'].size])
+        return pic
+
+    def mean_ms(x, mask=None):
+        x = np.asarray(x, dtype=float)
+        if mask is not None:
+            x = x[mask[:x.size]]
+        x = x[np.isfinite(x)]
+        return float(x.mean()) if x.size else None
+
+    m = measure(graph)
+    times = m['times']
     dt_med, dt_min = float(np.median(times)), float(times.min())
-
-    # kernel-level picture from one more replay of the same batch with HIP events around every launch of the dominant kernel
-    k_times, relin, k_name = np.zeros(0), np.zeros(0, np.int64), ''
-    if not dry:
-        dt_instr = batch(timing=True)
-        k_times = graph.kernel_times()                         # ms, one per sweep of the timed region
-        _, _, k_name = graph.kernel_timing()
-        graph.set_kernel_timing(0)
-        if args.steps <= 512:
-            relin = np.asarray(graph.relin_counts(args.steps), dtype=np.int64)
-    are = graph.are()
+    are = m['are']
+    exchange_used = getattr(graph, 'exchange', None)
+    alt = None
+    if world > 1 and not dry and args.exchange == 'auto' and exchange_used == 'rccl':
+        # the same job with the peer-store exchange (no collective call: reduce kernels store into the ranks' mailboxes over xGMI)
+        alt = try_peer_exchange(args, problem, local_rank, dist, torch, measure, graph)
+        if alt is not None and float(np.median(alt['times'])) < dt_med and alt.get('matches_rccl'):
+            m, alt = alt, dict(m, exchange='rccl')
+            times = m['times']
+            dt_med, dt_min = float(np.median(times)), float(times.min())
+            are = m['are']
+            exchange_used = 'peer'
+        elif alt is not None:
+            alt = dict(alt, exchange='peer')
     if args.dump_sweeps and rank == 0:
-        np.savez(args.dump_sweeps, kernel_ms=k_times, relin=relin, batch_s=times)
+        np.savez(args.dump_sweeps, clk_us=m['clk'], event_ms=m['ev_ms'], relin=m['relin'], batch_s=times)
+
+    pic = kernel_picture(m, F)
+    per_rank = None
+    if dist is not None and not dry and pic['n']:
+        mine = [mean_ms(pic[k], pic['ok']) or 0.0 for k in ('sweep', 'reduce', 'busy', 'finish')] + [mean_ms(pic['step'], pic['ok'][:-1]) or 0.0,
+                float(graph.F), float(graph.comm_info()['n_ranks'])]
+        t = torch.tensor(mine, dtype=torch.float64, device='cuda')
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        per_rank = [dict(rank=r, sweep_ms=v[0], reduce_and_exchange_ms=v[1], sweep_busy_ms=v[2], finish_ms=v[3], step_ms_device=v[4], n_factors=int(v[5]),
+                         ranks_reported_by_exchange=int(v[6])) for r, v in enumerate(x.cpu().tolist() for x in allr)]
 
     if rank == 0:
         info = dict(fused=False, n_blocks=0) if dry else graph.info()
@@ -280,55 +418,93 @@ def main():
         F_local, L_local = graph.F, graph.L
         fused = bool(info.get('fused'))
         lay = layout_bytes(F_local, L_local, C, info.get('n_blocks', 0), fused)
-        # steady = (almost) nobody relinearises: fewer than 1 factor in 1000 (they add < 0.1 % of the sweep's bytes)
-        steady = relin * 1000 < F if relin.size == k_times.size else np.ones(k_times.size, bool)
-        if not steady.any():
-            steady = np.ones(k_times.size, bool)
-        k_steady = float(k_times[steady].mean()) if k_times.size else 0.0
+        ms_step = dt_med / args.steps * 1e3
+        k_steady = k_med = k_min = 0.0
+        n_steady = 0
+        red_ms = None
+        if pic['n'] and fused:
+            sw = pic['sweep'][pic['ok']]
+            k_steady, k_med, k_min, n_steady = float(sw.mean()), float(np.median(sw)), float(sw.min()), int(sw.size)
+            red_ms = mean_ms(pic['reduce'], pic['ok'])
+            k_src = ("device clock stamped by the first workgroup of every kernel of one extra replay of the batch: kernel_avg_ms = sweep start -> "
+                     "reduce start (the interval rocprofv3 reports as the kernel's duration), kernel_busy_ms = first workgroup in -> last workgroup out")
+        elif m['ev_ms'].size:                                    # general sweep: HIP events only
+            ev_steady = pic['steady'][pic['ev_idx']] if pic['n'] else np.ones(m['ev_ms'].size, bool)
+            ev = m['ev_ms'][ev_steady] if ev_steady.any() else m['ev_ms']
+            k_steady, k_med, k_min, n_steady = float(ev.mean()), float(np.median(ev)), float(ev.min()), int(ev.size)
+            k_src = f"HIP events around every {EVENT_EVERY}-th launch, one extra replay of the batch"
+        else:
+            k_src = "none"
         achieved = lay / (k_steady * 1e-3) / 1e9 if k_steady else 0.0
         traffic, traffic_src = measured_traffic() if (world == 1 and fused and F == 1_000_000 and not dry) else (None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": k_name, "bytes_per_launch": lay,
+                "traffic": traffic, "kernel": m['k_name'], "bytes_per_launch": lay,
                 "bytes_model": "engine layout, DESIGN.md section 4: F*(31 doubles + 12 B) + L*36 doubles + camera tables",
-                "kernel_avg_ms": k_steady, "kernel_median_ms": float(np.median(k_times[steady])) if k_times.size else 0.0,
-                "kernel_min_ms": float(k_times[steady].min()) if k_times.size else 0.0,
-                "kernel_launches_timed": int(steady.sum()), "kernel_timing": "HIP events around every launch, separate replay of the batch",
+                "kernel_avg_ms": k_steady, "kernel_median_ms": k_med, "kernel_min_ms": k_min,
+                "kernel_launches_timed": n_steady, "kernel_timing": k_src,
                 "survey_equivalent_bytes": survey_bytes(F_local, L_local, C),
                 "survey_equivalent_gbs": survey_bytes(F_local, L_local, C) / (k_steady * 1e-3) / 1e9 if k_steady else 0.0}
+        if red_ms is not None:
+            roof["kernel_busy_ms"] = mean_ms(pic['busy'], pic['ok'])
+            roof["reduce_kernel"] = "k_cam_reduce_tree"
+            roof["reduce_avg_ms"] = red_ms
+            roof["step_ms_device"] = mean_ms(pic['step'], pic['ok'][:-1])
+            # a kernel cannot take longer than the step that contains it
+            roof["consistent"] = bool(k_steady + red_ms <= ms_step * 1.03)
+            if not roof["consistent"]:
+                print(f"[bench] WARNING: kernel {k_steady:.4f} ms + reduce {red_ms:.4f} ms > step {ms_step:.4f} ms", file=sys.stderr)
+        if m['ev_ms'].size and pic['n'] and fused:
+            ev_steady = pic['steady'][pic['ev_idx']]
+            if ev_steady.any():
+                roof["kernel_event_ms"] = float(m['ev_ms'][ev_steady].mean())
+                roof["kernel_event_note"] = (f"HIP events around every {EVENT_EVERY}-th launch of the same replay: includes the dispatch latency behind the "
+                                             "event's barrier packet, reported as a cross-check only")
         if traffic and k_steady:
-            roof["traffic_source"] = f"profiles/{traffic_src}"
+            roof["traffic_source"] = f"profiles/{traffic_src}: committed rocprofv3 PMC passes of this command, NOT measured by this run"
             roof["traffic_gbs"] = traffic / (k_steady * 1e-3) / 1e9
             roof["traffic_frac"] = roof["traffic_gbs"] / HBM_PEAK_GBS
-        if k_times.size and (~steady).any():
+        if pic['n'] and fused and (~pic['steady']).any():
+            ns, relin = ~pic['steady'], m['relin']
             full = relin * 2 > F
-            roof["relinearising_sweeps"] = {"count": int((~steady).sum()), "kernel_avg_ms": float(k_times[~steady].mean()),
-                                            "kernel_max_ms": float(k_times[~steady].max()),
-                                            "factors_per_sweep_mean": float(relin[~steady].mean()), "factors_per_sweep_max": int(relin.max()),
+            roof["relinearising_sweeps"] = {"count": int(ns.sum()), "kernel_avg_ms": mean_ms(pic['sweep'], ns),
+                                            "kernel_max_ms": float(np.nanmax(pic['sweep'][ns])),
+                                            "factors_per_sweep_mean": float(relin[ns].mean()), "factors_per_sweep_max": int(relin.max()),
                                             "extra_bytes_per_factor": 72}
             if full.any():
-                roof["relinearising_sweeps"]["all_factors"] = {"count": int(full.sum()), "kernel_avg_ms": float(k_times[full].mean())}
+                roof["relinearising_sweeps"]["all_factors"] = {"count": int(full.sum()), "kernel_avg_ms": mean_ms(pic['sweep'], full)}
+        par = "single GPU"
+        if world > 1:
+            how = {"rccl": "RCCL all-gather of camera partial sums per sweep", "peer": "peer-store exchange of camera partial sums per sweep (no collective)",
+                   "python": "all_gather_into_tensor of camera partial sums per sweep"}.get(exchange_used, str(exchange_used))
+            par = f"landmark-sharded x{world}, {how}"
         out = {
             "metric": "GBP iterations/sec (whole node), 1M-factor BA graph" if F == 1_000_000 else f"GBP iterations/sec, {F}-factor BA graph",
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_med / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "fixture file (tests/golden/data)" if args.bal else "synthetic",
             "config": {"workload": f"{workload} {C} cams x {L} landmarks x {F} reprojection factors "
                                    + ("" if args.bal else "(gbp_amd.synthetic.make_synthetic seed 0), ") + "ba.py defaults, loss=None",
                        "n_cams": C, "n_lmks": L, "n_factors": F,
-                       "parallelism": f"landmark-sharded x{world}, RCCL all-gather of camera partial sums per sweep" if world > 1 else "single GPU",
+                       "parallelism": par, "exchange": exchange_used if (world > 1 or args.sharded) else None,
                        "sweep": "fused" if fused else "general",
                        "loop": ("python" if (args.python_loop or dry) else "in-library") if (world > 1 or args.sharded) else "gbp_ba_iterate"},
             "timing": {"protocol": "state restored before every batch; W warm-up + K timed sweeps between barrier+synchronize; median over batches",
                        "batches": int(times.size), "timed_seconds": float(times.sum()),
-                       "ms_per_step_median": dt_med / args.steps * 1e3, "ms_per_step_min": dt_min / args.steps * 1e3,
+                       "ms_per_step_median": ms_step, "ms_per_step_min": dt_min / args.steps * 1e3,
                        "ms_per_step_first": float(times[0]) / args.steps * 1e3},
             "roofline": roof,
             "are_after": are,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if alt is not None:
+            at = alt['times']
+            out["other_exchange"] = {"exchange": alt.get('exchange'), "value": args.steps / float(np.median(at)), "ms_per_step": float(np.median(at)) / args.steps * 1e3,
+                                     "batches": int(at.size), "camera_beliefs_match": alt.get('matches_rccl', alt.get('matches'))}
         if dry:
             out["dry_run"] = True
         if world == 1 and not args.no_cpu_baseline and not dry:
-            out["cpu_baseline"] = cpu_baseline(problem)
+            out["cpu_baseline"] = cpu_baseline(problem, engine=graph)
             if args.bal and F <= 50_000:
                 out["cpu_baseline_numpy"] = cpu_baseline_numpy(problem)
         os.write(json_fd, (json.dumps(out) + '\n').encode())

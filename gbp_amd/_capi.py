@@ -14,6 +14,7 @@ _ip = ct.POINTER(ct.c_int32)
 _bp = ct.POINTER(ct.c_uint8)
 
 LOSS = {None: 0, 'None': 0, 'none': 0, 'huber': 1, 'constant': 2}
+ABI_VERSION = 2
 FLAG_NO_FUSED = 1
 FLAG_DEVICE_INPUT = 2
 CAM_PARTIAL_DOUBLES = 27
@@ -86,6 +87,8 @@ SIGNATURES = {
     'gbp_ba_get_relin_counts': (ct.c_int, [ct.c_void_p, _ip, ct.c_int32]),
     'gbp_ba_eval_fn': (ct.c_int, [_dp, ct.c_int32, _dp, _dp, _dp, _dp, ct.c_int32]),
     'gbp_ba_get_kernel_times': (ct.c_int, [ct.c_void_p, _dp, ct.c_int32, ct.POINTER(ct.c_int32)]),
+    'gbp_ba_get_sweep_clocks': (ct.c_int, [ct.c_void_p, _dp, ct.c_int32, ct.POINTER(ct.c_int32)]),
+    'gbp_ba_comm_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     'gbp_ba_set_iters_since_relin': (ct.c_int, [ct.c_void_p, _ip]),
     'gbp_ba_fill_iters_since_relin': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_shard_begin': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_void_p]),
@@ -174,8 +177,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gbp_abi_version() != 1:
-            raise ImportError(f"libgbp_hip.so ABI {lib.gbp_abi_version()} != 1")
+        if lib.gbp_abi_version() != ABI_VERSION:
+            raise ImportError(f"libgbp_hip.so ABI {lib.gbp_abi_version()} != {ABI_VERSION}")
         _lib = lib
     return _lib
 

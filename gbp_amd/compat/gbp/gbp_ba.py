@@ -293,10 +293,12 @@ class BAFactorGraph:
         self._invalidate()
 
     def weaken_priors(self, weakening_factor):
+        self._flush()                     # priors written through node.prior first, or the next flush would undo the weakening
         self._engine.weaken_priors(weakening_factor)
         self._invalidate()
 
     def set_priors_var(self, priors):
+        self._flush()
         self._engine.set_priors_var(priors)
         self._invalidate()
 

@@ -98,6 +98,9 @@ struct gbp_ba {
     std::vector<hipEvent_t> ev;                  // pairs
     size_t ev_used = 0;
     const char *dominant = "k_factor_tile";
+    // device-clock stamps of instrumented sweeps: [CLK_RING][6] = {sweep start, end, reduce start, end, finish start, end}
+    unsigned long long *d_clk = nullptr, *clk_cur = nullptr;
+    int clk_used = 0, clk_rate_khz = 0;
     // per-sweep count of relinearising factors: ring of device counters, half of it cleared whenever the sweep index
     // enters it, so the last RELIN_RING/2 sweeps are always readable
     int *d_relin_ring = nullptr;
@@ -126,6 +129,7 @@ struct gbp_ba {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 constexpr int RELIN_RING = 1024;
+constexpr int CLK_RING = 4096;
 
 template <typename T>
 static int dev_alloc(gbp_ba *h, T **out, size_t n, bool zero = true)
@@ -274,6 +278,7 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
     if (!h->p.C) return GBP_OK;
     PeerWait w{};
     if (wait) w = *wait;
+    w.clk = h->clk_cur ? h->clk_cur + 4 : nullptr;
     hipLaunchKernelGGL(k_cam_finish, dim3((h->p.C + FINISH_BLOCK / 64 - 1) / (FINISH_BLOCK / 64)), dim3(FINISH_BLOCK), 0, h->stream, h->p, gathered,
                        n_parts, stride, w);
     HIPCHK(hipGetLastError());
@@ -316,6 +321,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
                        bool *finished = nullptr, bool defer_big = false, const PeerOut *peer = nullptr)
 {
     if (finished) *finished = false;
+    h->clk_cur = (h->timing && h->d_clk && h->clk_used < CLK_RING) ? h->d_clk + 6 * (size_t)h->clk_used++ : nullptr;
     if (with_messages) {
         const int slot = (int)(h->sweep_count % RELIN_RING);
         if (slot % (RELIN_RING / 2) == 0)
@@ -338,7 +344,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         static const bool no_rev = getenv("GBP_NO_REVERSE") != nullptr;
         const int reverse = no_rev ? 0 : (int)(h->walk_parity & 1u);
         h->walk_parity ^= 1u;
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse, peer);
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse, peer, h->clk_cur);
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (finished) *finished = finish != 0;
         return GBP_OK;
@@ -375,6 +381,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -400,6 +407,7 @@ int rccl_load(const char *path)
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(lib, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(lib, "ncclCommCount"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
         return fail(GBP_ESTATE, "librccl.so lacks an expected entry point");
     g_rccl = r;
@@ -1058,7 +1066,7 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
         int rc = h->xch_fn(h->xch_ctx, nullptr, nullptr, 0, h->stream);
         if (rc != GBP_OK) return rc < 0 ? rc : fail(GBP_EHIP, "the rendezvous function returned %d", rc);
     }
-    PeerWait w{peer_flag(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1};
+    PeerWait w{peer_flag(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1, nullptr};
     CHK(launch_cam_finish(h, peer_data(h, pe.mailbox, n, half, 0), n, peer_c27(h), &w));
     if (big) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return GBP_OK;
@@ -1584,7 +1592,9 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
-    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0 || hd.version != 4) return fail(GBP_EINVAL, "not a GBP state blob (magic/version)");
+    if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0) return fail(GBP_EINVAL, "not a GBP state blob (magic)");
+    if (hd.version != 4)            // 1-3: dense / core-only message layouts of earlier builds -- not convertible without the Jacobians they were made with
+        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 4; INTEGRATION.md)", hd.version);
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)
@@ -1611,6 +1621,56 @@ int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable)
     h->timing_every = enable > 1 ? enable : 1;
     h->timing_tick = 0;
     h->ev_used = 0;
+    h->clk_used = 0; h->clk_cur = nullptr;
+    if (enable) {
+        if (!h->d_clk) {
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_clk), sizeof(unsigned long long) * 6 * CLK_RING));
+            h->allocs.push_back(h->d_clk);
+            HIPCHK(hipDeviceGetAttribute(&h->clk_rate_khz, hipDeviceAttributeWallClockRate, h->device));
+        }
+        hipLaunchKernelGGL(k_clk_init, dim3((6 * CLK_RING + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d_clk, 6 * CLK_RING);
+        HIPCHK(hipGetLastError());
+    }
+    return GBP_OK;
+}
+
+int gbp_ba_get_sweep_clocks(gbp_ba_t *h, double *us6, int32_t cap, int32_t *n_sweeps)
+{
+    ENTER(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int n = std::min(h->clk_used, CLK_RING);
+    if (n_sweeps) *n_sweeps = n;
+    if (!us6 || !n || cap <= 0) return GBP_OK;
+    std::vector<unsigned long long> raw;
+    CHK(download(h, raw, h->d_clk, 6 * (size_t)n));
+    unsigned long long t0 = ~0ull;
+    for (unsigned long long v : raw) if (v != 0ull && v != ~0ull) t0 = std::min(t0, v);
+    const double us_per_tick = h->clk_rate_khz > 0 ? 1e3 / (double)h->clk_rate_khz : 0.01;
+    for (int i = 0; i < n && i < cap; ++i)
+        for (int k = 0; k < 6; ++k) {
+            const unsigned long long v = raw[6 * (size_t)i + k];
+            us6[6 * (size_t)i + k] = (v == 0ull || v == ~0ull) ? NAN : (double)(v - t0) * us_per_tick;
+        }
+    return GBP_OK;
+}
+
+int gbp_ba_comm_info(gbp_ba_t *h, int32_t *kind, int32_t *rank, int32_t *n_ranks)
+{
+    ENTER(h);
+    int k = GBP_COMM_NONE, n = h->xch_ranks;
+    if (h->peer.connected) { k = GBP_COMM_PEER; n = h->peer.n_ranks; }
+    else if (h->comm) {
+        k = GBP_COMM_RCCL;
+        if (g_rccl.CommCount) {
+            int cnt = 0;
+            const ncclResult_t rc = g_rccl.CommCount(h->comm, &cnt);
+            if (rc != ncclSuccess) return fail(GBP_EHIP, "ncclCommCount failed: %s", g_rccl.GetErrorString(rc));
+            n = cnt;                                         // what RCCL itself says
+        }
+    } else if (h->xch_fn) k = GBP_COMM_CALLBACK;
+    if (kind) *kind = k;
+    if (rank) *rank = h->xch_rank;
+    if (n_ranks) *n_ranks = n;
     return GBP_OK;
 }
 

@@ -76,7 +76,20 @@ struct FusedArgs {
                                 // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results),
                                 // 32 only the first round of the accumulation (same-camera duplicates of a tile dropped)
     unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
+    unsigned long long *clk;    // instrumented runs (gbp_ba_set_kernel_timing): {earliest workgroup start, latest workgroup end} of this
+                                // launch on the device's constant-rate clock (wall_clock64), or NULL.  HIP events around a launch
+                                // also time the dispatch after the event's barrier packet (~5-8 us); this does not.
 };
+
+// first / last thing a workgroup does in an instrumented launch: min over the workgroups of the start, max of the end
+GBP_DEV void clk_begin(unsigned long long *clk) { if (clk && threadIdx.x == 0) atomicMin(clk, (unsigned long long)wall_clock64()); }
+GBP_DEV void clk_end(unsigned long long *clk)
+{
+    if (!clk) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the workgroup's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)wall_clock64());
+}
 
 // Phase profile of the persistent loop (tools/phase_profile.py builds the library with -DGBP_PHASE_TIMING): every wave adds
 // the s_memtime ticks it spends between consecutive marks into its own row.  Off in the product build (no code at all).
@@ -106,6 +119,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     double *wp = smem + acc_even + NWAVES * WAVE_LDS_DOUBLES + wave * WAVE_PRIOR_DOUBLES;      // [24][10] prior | rows
     int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES));   // {next, done}
     const int tid = threadIdx.x, lane = tid & 63;
+    clk_begin(a.clk);
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     }
     GBP_PH(11);                                            // table write-out
     GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
+    clk_end(a.clk);
 }
 
 // More cameras than one LDS table holds (C > 516): the sweep above adds up the messages to the first group of cameras; one
@@ -346,10 +361,11 @@ constexpr int RED_THREADS = 1024;      // the copy into LDS is the latency of th
                                        // (55 KB at 256 workgroups) in flight at once, four 16-byte loads per thread (256 threads with a
                                        // rolled loop: 8.1 us at C = 500 and 9.0 us for the 63 cameras of fr1desk)
 __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
-                                                                 double *__restrict__ partial, int finish, PeerOut peer)
+                                                                 double *__restrict__ partial, int finish, PeerOut peer, unsigned long long *clk)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][27] | red[RED_PARTS][27] | tot[27]
     const int c = blockIdx.x, n = n_blocks * TROW, tid = threadIdx.x;
+    clk_begin(clk);
     double *red = sh + ((n + 1) & ~1), *tot = red + RED_PARTS * 27;
     const double *src = block_partials + (size_t)c * n;
     if (((size_t)c * n & 1) == 0) {
@@ -398,6 +414,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
         r2[0] = make_double2(mu[0], mu[1]); r2[1] = make_double2(mu[2], mu[3]); r2[2] = make_double2(mu[4], mu[5]);
         rec[33] = 0.0;
     }
+    // (no end stamp here: waiting for the whole workgroup at the end of a launch this short -- 500 workgroups that leave one lane
+    //  behind for the 6x6 solve -- made the launch 5 us longer; the next kernel's start stamp closes the interval instead)
 }
 
 // ------------------------------------------------------------------------------------ host --
@@ -486,7 +504,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 #ifdef GBP_PHASE_TIMING
     if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
 #endif
-    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, env_dbg ? atoi(env_dbg) : 0, d_phase};
+    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, env_dbg ? atoi(env_dbg) : 0, d_phase, nullptr};
     pl.d_blk = d_blk;
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
@@ -505,9 +523,10 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 // returns 0 or a hipError_t value
 inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int local_relin, double *partial, hipStream_t stream,
                         int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false, int reverse = 0,
-                        const PeerOut *peer = nullptr)
+                        const PeerOut *peer = nullptr, unsigned long long *clk = nullptr)
 {
     pl.args.reverse = reverse;
+    pl.args.clk = clk;                                      // [0..1] the sweep kernel's stamps, [2..3] the reduce kernel's
     Params p = p0;
     p.robustify = robustify; p.local_relin = local_relin;
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
@@ -529,7 +548,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     const size_t red_shmem = sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27);
     PeerOut po{};
     if (peer) po = *peer;
-    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po);
+    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po, clk ? clk + 2 : nullptr);
     return (int)hipGetLastError();
 }
 

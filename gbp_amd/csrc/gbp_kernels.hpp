@@ -624,6 +624,7 @@ struct PeerWait {
     unsigned long long seq;
     long long timeout_ticks;                          // wall_clock64 ticks (100 MHz): a peer that never arrives must not hang the GPU
     int *err;                                         // set to 1 on time-out (reported by gbp_ba_sync)
+    unsigned long long *clk;                          // instrumented runs: {earliest workgroup start, latest end} of the finish launch, or NULL
 };
 
 // No fences: a system-scope release / acquire fence on gfx950 writes back / invalidates a whole L2 (8000 waves doing that after the
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(BLOCK) void k_peer_push(const double *__restrict__ 
 constexpr int FINISH_BLOCK = 256;
 __global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const double *gathered, int n_parts, size_t part_stride, PeerWait wait)
 {
+    if (wait.clk && threadIdx.x == 0) atomicMin(wait.clk, (unsigned long long)wall_clock64());
     if (wait.flags) {
         if (threadIdx.x < 64) {
             bool ok = true;
@@ -702,7 +704,18 @@ __global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const dou
 #pragma unroll
         for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
         rec[33] = 0.0;
+        if (wait.clk) {                                     // (per camera, not per workgroup: waves leave independently)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicMax(wait.clk + 1, (unsigned long long)wall_clock64());
+        }
     }
+}
+
+// instrumented runs: the stamp ring starts as {max, 0} pairs (atomicMin / atomicMax targets)
+__global__ void k_clk_init(unsigned long long *clk, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) clk[i] = (i & 1) ? 0ull : ~0ull;
 }
 
 // ----------------------------------------------------------------------------- diagnostics --

@@ -67,7 +67,10 @@ class BAEngine:
 
     def _init_from_device(self, K, cam_means, lmk_means, meas, cam_idx, lmk_idx, sizes, gauss_noise_std, loss, Nstds, beta,
                           num_undamped_iters, min_linear_iters, eta_damping, device, fused):
-        K = f64(np.asarray(K, dtype=np.float64).reshape(-1), (4,))
+        K = np.asarray(K, dtype=np.float64)
+        if K.shape == (3, 3):                                # the host constructor takes either form too
+            K = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+        K = f64(K.reshape(-1), (4,))
         self.C, self.L, self.F = (int(v) for v in sizes)
         if loss not in _capi.LOSS:
             raise ValueError(f"unknown loss {loss!r} (None, 'huber', 'constant')")
@@ -351,6 +354,21 @@ class BAEngine:
         out = np.empty(n.value)
         check(self._lib.gbp_ba_get_kernel_times(self._h, dptr(out), n.value, ct.byref(n)))
         return out
+
+    def sweep_clocks(self):
+        """Device-clock stamps of every sweep since set_kernel_timing, microseconds since the first stamp: (n, 6) =
+        fused sweep start, end | camera reduce start, end | camera finish start, end (NaN where a kernel did not run)."""
+        n = ct.c_int32()
+        check(self._lib.gbp_ba_get_sweep_clocks(self._h, None, 0, ct.byref(n)))
+        out = np.full((n.value, 6), np.nan)
+        if n.value:
+            check(self._lib.gbp_ba_get_sweep_clocks(self._h, dptr(out), n.value, ct.byref(n)))
+        return out
+
+    def comm_info(self):
+        k, r, n = ct.c_int32(), ct.c_int32(), ct.c_int32()
+        check(self._lib.gbp_ba_comm_info(self._h, ct.byref(k), ct.byref(r), ct.byref(n)))
+        return dict(kind=['none', 'callback', 'rccl', 'peer'][k.value], rank=r.value, n_ranks=n.value)
 
     def check_layout(self):
         """Debug kernel: number of slots that do not decode to the reference factor they hold (0 for a sound layout)."""

@@ -80,11 +80,25 @@ class _HipShard:
         elif exchange == 'peer':
             if threads:                                      # logical ranks must not spin on each other: rendezvous hook between
                 self.engine.set_exchange(lambda s, r, n, st: dist.device_exchange(rank, s, r, n, st), rank, world, False)
-            mine = self.engine.peer_export(world, same_process=threads)
+            # every rank reaches every collective below whatever fails locally: a failure travels as data, then all ranks raise
+            try:
+                mine = self.engine.peer_export(world, same_process=threads)
+            except Exception as e:                           # noqa: BLE001
+                mine = f"error: {e}"
             handles = [None] * world
             dist.all_gather_object(handles, mine)
-            self.engine.peer_connect(rank, handles, same_process=threads, rendezvous=threads)
-            dist.barrier()                                   # nobody stores into a mailbox its owner has not set up yet
+            bad = [h for h in handles if not isinstance(h, (bytes, bytearray))]
+            err = None
+            if not bad:
+                try:
+                    self.engine.peer_connect(rank, handles, same_process=threads, rendezvous=threads)
+                except Exception as e:                       # noqa: BLE001
+                    err = f"error: {e}"
+            oks = [None] * world
+            dist.all_gather_object(oks, err)                 # also the barrier: nobody stores into a mailbox its owner has not set up yet
+            bad += [o for o in oks if o is not None]
+            if bad:
+                raise RuntimeError(f"peer-store exchange could not be set up ({bad[0]})")
         elif exchange == 'rccl':
             # rank 0 may fail to make the id (librccl not loadable): everybody must still leave the broadcast
             ids = [None]
@@ -254,6 +268,12 @@ class ShardedBA:
 
     def kernel_times(self):
         return self.engine.kernel_times()
+
+    def sweep_clocks(self):
+        return self.engine.sweep_clocks()
+
+    def comm_info(self):
+        return self.engine.comm_info()
 
     def relin_counts(self, n):
         """Factors that relinearised in each of the last n sweeps, summed over the ranks."""

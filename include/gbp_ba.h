@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GBP_ABI_VERSION 1
+#define GBP_ABI_VERSION 2      /* 2: gbp_ba_info's fused_path counts camera groups, state blobs are version 4, peer-store exchange, sweep clocks */
 
 enum {
     GBP_OK = 0,
@@ -198,6 +198,18 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h);
  * brackets only every n-th launch (two event records per sweep are not free: ~6 us of a 125 us sweep) */
 int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
 int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);
+/* the same instrumented run also stamps, inside the kernels, the device's constant-rate clock (wall_clock64): per sweep since
+ * gbp_ba_set_kernel_timing six stamps in MICROSECONDS since the first one -- {fused sweep: earliest workgroup start, latest
+ * workgroup end; camera reduce: start, (unused); camera finish (sharded only): start, end}; NaN where a kernel did not run or
+ * does not stamp.  Consecutive START stamps tile the stream's timeline the way rocprofv3's kernel durations do (a kernel's
+ * interval then includes its own drain and the next dispatch).  HIP
+ * events around a launch include the dispatch latency behind the event's barrier packet (5-8 us); the stamps do not, and
+ * they do not serialise the stream.  Up to 4096 sweeps per enable. */
+int gbp_ba_get_sweep_clocks(gbp_ba_t *h, double *us6, int32_t cap_sweeps, int32_t *n_sweeps);
+/* which exchange the sharded loop uses and what it says about itself: kind GBP_COMM_*, this rank, the rank count (for RCCL:
+ * ncclCommCount of the library's communicator) */
+enum { GBP_COMM_NONE = 0, GBP_COMM_CALLBACK = 1, GBP_COMM_RCCL = 2, GBP_COMM_PEER = 3 };
+int gbp_ba_comm_info(gbp_ba_t *h, int32_t *kind, int32_t *rank, int32_t *n_ranks);
 int gbp_ba_get_kernel_times(gbp_ba_t *h, double *ms, int32_t cap, int32_t *n_launches);   /* each bracketed launch, in order; call BEFORE get_kernel_timing (which resets) */
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);   /* fused_path: 0 = general sweep, g >= 1 = fused sweep with g camera groups (g - 1 extra k_cam_pass launches) */
 int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols);   /* debug builds with -DGBP_PHASE_TIMING only (tools/phase_profile.py): per-wave time per phase of the last fused sweep */

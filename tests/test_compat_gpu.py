@@ -86,6 +86,18 @@ def test_factor_graph_surface_of_the_device_graph(compat_path):
     assert np.allclose(graph.lmk_nodes[5].belief.lam, 3.0 * lam0)           # no messages yet: belief = prior
     with pytest.raises(AttributeError):
         v.mu = np.zeros(3)
+    # a prior written through the view and weakened right after (gbp_ba.py:36-42) is the weakened WRITTEN prior: the pending host
+    # write reaches the device before weaken_priors / set_priors_var touch the device priors, and is not replayed over them later
+    w = graph.lmk_nodes[9]
+    lam9 = w.prior.lam.copy()
+    w.prior.lam = 5.0 * lam9
+    graph.weaken_priors(0.5)
+    assert np.allclose(graph._engine.priors()[3][9], 2.5 * lam9)
+    graph.update_all_beliefs()
+    assert np.allclose(graph._engine.priors()[3][9], 2.5 * lam9) and np.allclose(graph.lmk_nodes[9].prior.lam, 2.5 * lam9)
+    assert np.allclose(graph._engine.priors()[3][5], 1.5 * lam0)
+    graph.weaken_priors(2.0)                                                  # back to where the checks below expect the priors
+    graph.update_all_beliefs()
     # batch solution of the linearised problem (gbp.py:94-144) against the same thing assembled from the views
     eta, lam = graph.joint_distribution_inf()
     assert eta.shape == (60 + 1920,) and np.allclose(lam, lam.T)

@@ -12,6 +12,7 @@ from gbp_amd.synthetic import BAProblem, make_synthetic
 pytestmark = pytest.mark.gpu
 
 COMPARED = {}
+ESCAPES = []
 N_SEEDS = int(os.environ.get('GBP_FUZZ_SEEDS', 24))
 
 
@@ -118,6 +119,7 @@ def test_random_shapes_against_oracle(oracle_mod, seed):
             spread, espread = third_opinion(p, cfg, flags[:k + 1], o)
             assert max(gaps) < max(1e-6, 4.0 * spread), (seed, compared, gaps, spread, p.n_cams, p.n_lmks, p.n_factors)
             assert max(egaps) <= max(etol, 4.0 * espread * abs(o.energy())), (seed, 'energy', egaps, espread)
+            ESCAPES.append(seed)                            # (bounded in test_fuzz_was_not_vacuous: the escape must stay the exception)
             break                                           # ill-conditioned from here on: nothing more to learn from this seed
         for e in engines:
             se = e.relin_state()
@@ -132,3 +134,6 @@ def test_random_shapes_against_oracle(oracle_mod, seed):
 def test_fuzz_was_not_vacuous():
     """Most sweeps of most seeds must have been comparable (the health filter may only cut the odd blown-up run short)."""
     assert len(COMPARED) == N_SEEDS and sum(COMPARED.values()) >= 0.6 * 8 * N_SEEDS, COMPARED
+    # the third-opinion escape (a GPU-oracle gap above 1e-6 excused by an equally large gap between two CPU implementations) is for the
+    # odd ill-conditioned relinearisation: at most one seed in 24 may take it, everything before that sweep was held to 1e-6
+    assert len(ESCAPES) <= max(1, N_SEEDS // 24), ESCAPES

@@ -68,8 +68,9 @@ for size, F, L, C in (('1m', 1_000_000, 100_000, 500), ('10m', 10_000_000, 1_000
              "traffic_bytes_per_launch": fetch_b + write_b, "read_bytes": fetch_b, "write_bytes": write_b,
              "dispatches": [fe[1], wr[1]]}
         if cal:
-            t["calibration"] = {"kernel": "k_cam_reduce_tree", "expected_read_bytes": n_blocks * C * 27 * 8, "fetch_size_kb_raw": cal[0],
-                                "ratio_expected_over_raw": n_blocks * C * 27 * 8 / (cal[0] * 1000.0)}
+            # the reduce kernel reads exactly the workgroup tables: n_blocks x C rows of 28 doubles (27 sums + pad, gbp_fused.hpp TROW)
+            t["calibration"] = {"kernel": "k_cam_reduce_tree", "expected_read_bytes": n_blocks * C * 28 * 8, "fetch_size_kb_raw": cal[0],
+                                "ratio_expected_over_raw": n_blocks * C * 28 * 8 / (cal[0] * 1000.0)}
         if ka:
             t["kernel_avg_us_rocprofv3"] = ka[0] / 1e3
             t["kernel_calls"] = ka[1]
@@ -77,13 +78,15 @@ for size, F, L, C in (('1m', 1_000_000, 100_000, 500), ('10m', 10_000_000, 1_000
             t["frac_of_8tbs"] = (fetch_b + write_b) / ka[0] / 8000.0
         if line:
             t["layout_bytes_per_launch"] = line["roofline"]["bytes_per_launch"]
-            t["bench_kernel_avg_us_hip_events"] = line["roofline"]["kernel_avg_ms"] * 1e3
+            t["bench_kernel_avg_us_device_clock"] = line["roofline"]["kernel_avg_ms"] * 1e3
+            t["bench_kernel_avg_us_hip_events_every_7th"] = (line["roofline"].get("kernel_event_ms") or 0.0) * 1e3
+            t["bench_reduce_avg_us_device_clock"] = (line["roofline"].get("reduce_avg_ms") or 0.0) * 1e3
             t["bench_value_it_s"] = line["value"]
         traffic[size] = t
 if traffic:
     doc = {"round": tag, "kernel": "k_sweep_wat<0, 8> (k_sweep_fused)",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh); FETCH_SIZE doubled "
-                     "(gfx950, MI355X_MICROARCH.md 'HBM'), checked against k_cam_reduce_tree, whose read is exactly 256 x C x 27 doubles",
+                     "(gfx950, MI355X_MICROARCH.md 'HBM'), checked against k_cam_reduce_tree, whose read is exactly 256 x C x 28 doubles",
            "traffic_bytes_per_launch": traffic.get('1m', {}).get('traffic_bytes_per_launch'), "sizes": traffic}
     json.dump(doc, open(os.path.join(dst, f'{tag}_hbm_traffic.json'), 'w'), indent=1)
 
