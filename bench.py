@@ -339,8 +339,10 @@ def main():
             # constant-rate clock (first workgroup in, last workgroup out), and HIP events bracket every EVENT_EVERY-th launch of
             # the dominant kernel as a cross-check (an event pair around a launch also times the dispatch behind the event's
             # barrier packet and serialises the stream, so it is neither put around every launch nor used for the roofline).
-            batch(timing=EVENT_EVERY)
+            batch(timing=1 << 30)                              # stamps only (events around the first launch alone)
             m['clk'] = graph.sweep_clocks()[:args.steps]
+            graph.set_kernel_timing(0)
+            batch(timing=EVENT_EVERY)
             m['ev_ms'] = graph.kernel_times()
             _, _, m['k_name'] = graph.kernel_timing()
             graph.set_kernel_timing(0)
@@ -356,12 +358,11 @@ def main():
         pic = dict(n=n)
         if not n:
             return pic
-        # START stamps tile the timeline like rocprofv3's kernel durations do: a kernel's interval runs from its first workgroup to the
-        # first workgroup of the next kernel (its own drain and the next dispatch included).  `busy` is first workgroup in -> last out.
+        # START stamps tile the timeline like rocprofv3's kernel durations do: a kernel's interval runs from its workgroup 0 to
+        # workgroup 0 of the next kernel (its own drain and the next dispatch included).
         step = np.diff(clk[:, 0]) * 1e-3                          # sweep start to next sweep start
         nxt = np.append(clk[1:, 0], np.nan)                      # start of the next sweep
         sweep = (clk[:, 2] - clk[:, 0]) * 1e-3
-        busy = (clk[:, 1] - clk[:, 0]) * 1e-3
         sharded_step = np.isfinite(clk[:, 4])
         reduce_ = (np.where(sharded_step, clk[:, 4], nxt) - clk[:, 2]) * 1e-3     # (with an exchange in between: reduce + exchange, see xch)
         finish = (nxt - clk[:, 4]) * 1e-3
@@ -370,7 +371,7 @@ def main():
         if not steady.any():
             steady = np.ones(n, bool)
         ok = steady & np.isfinite(sweep)
-        pic.update(sweep=sweep, busy=busy, reduce=reduce_, finish=finish, xch=xch, step=step, steady=steady, ok=ok,
+        pic.update(sweep=sweep, reduce=reduce_, finish=finish, xch=xch, step=step, steady=steady, ok=ok,
                    ev_idx=np.arange(0, n, EVENT_EVERY)[:m['ev_ms'].size])
         return pic
 
@@ -404,13 +405,13 @@ def main():
     pic = kernel_picture(m, F)
     per_rank = None
     if dist is not None and not dry and pic['n']:
-        mine = [mean_ms(pic[k], pic['ok']) or 0.0 for k in ('sweep', 'reduce', 'busy', 'finish')] + [mean_ms(pic['step'], pic['ok'][:-1]) or 0.0,
+        mine = [mean_ms(pic[k], pic['ok']) or 0.0 for k in ('sweep', 'reduce', 'finish')] + [mean_ms(pic['step'], pic['ok'][:-1]) or 0.0,
                 float(graph.F), float(graph.comm_info()['n_ranks'])]
         t = torch.tensor(mine, dtype=torch.float64, device='cuda')
         allr = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allr, t)
-        per_rank = [dict(rank=r, sweep_ms=v[0], reduce_and_exchange_ms=v[1], sweep_busy_ms=v[2], finish_ms=v[3], step_ms_device=v[4], n_factors=int(v[5]),
-                         ranks_reported_by_exchange=int(v[6])) for r, v in enumerate(x.cpu().tolist() for x in allr)]
+        per_rank = [dict(rank=r, sweep_ms=v[0], reduce_and_exchange_ms=v[1], finish_ms=v[2], step_ms_device=v[3], n_factors=int(v[4]),
+                         ranks_reported_by_exchange=int(v[5])) for r, v in enumerate(x.cpu().tolist() for x in allr)]
 
     if rank == 0:
         info = dict(fused=False, n_blocks=0) if dry else graph.info()
@@ -426,8 +427,8 @@ def main():
             sw = pic['sweep'][pic['ok']]
             k_steady, k_med, k_min, n_steady = float(sw.mean()), float(np.median(sw)), float(sw.min()), int(sw.size)
             red_ms = mean_ms(pic['reduce'], pic['ok'])
-            k_src = ("device clock stamped by the first workgroup of every kernel of one extra replay of the batch: kernel_avg_ms = sweep start -> "
-                     "reduce start (the interval rocprofv3 reports as the kernel's duration), kernel_busy_ms = first workgroup in -> last workgroup out")
+            k_src = ("device clock stamped by workgroup 0 of every kernel of one extra replay of the batch: kernel_avg_ms = sweep start -> "
+                     "reduce start, the interval rocprofv3 reports as the kernel's duration (consecutive kernels tile the stream's timeline)")
         elif m['ev_ms'].size:                                    # general sweep: HIP events only
             ev_steady = pic['steady'][pic['ev_idx']] if pic['n'] else np.ones(m['ev_ms'].size, bool)
             ev = m['ev_ms'][ev_steady] if ev_steady.any() else m['ev_ms']
@@ -445,7 +446,6 @@ def main():
                 "survey_equivalent_bytes": survey_bytes(F_local, L_local, C),
                 "survey_equivalent_gbs": survey_bytes(F_local, L_local, C) / (k_steady * 1e-3) / 1e9 if k_steady else 0.0}
         if red_ms is not None:
-            roof["kernel_busy_ms"] = mean_ms(pic['busy'], pic['ok'])
             roof["reduce_kernel"] = "k_cam_reduce_tree"
             roof["reduce_avg_ms"] = red_ms
             roof["step_ms_device"] = mean_ms(pic['step'], pic['ok'][:-1])

@@ -72,6 +72,10 @@ SIGNATURES = {
     'gbp_ba_weaken_priors': (ct.c_int, [ct.c_void_p, ct.c_double]),
     'gbp_ba_update_beliefs': (ct.c_int, [ct.c_void_p]),
     'gbp_ba_iterate': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
+    'gbp_ba_robustify': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_relinearise': (ct.c_int, [ct.c_void_p]),
+    'gbp_ba_compute_messages': (ct.c_int, [ct.c_void_p, ct.c_int32]),
+    'gbp_ba_compute_factors': (ct.c_int, [ct.c_void_p]),
     'gbp_ba_are': (ct.c_int, [ct.c_void_p, _dp]),
     'gbp_ba_energy': (ct.c_int, [ct.c_void_p, _dp]),
     'gbp_ba_residual_sums': (ct.c_int, [ct.c_void_p, _dp]),

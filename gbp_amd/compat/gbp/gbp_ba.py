@@ -319,30 +319,28 @@ class BAFactorGraph:
         self._engine.iterate(n, robustify=robustify, local_relin=local_relin)
         self._invalidate()
 
-    # The reference lets a caller run the four stages of a sweep one by one (gbp.py:46-84).  On the device they are ONE
-    # kernel -- a factor's messages are formed in the registers that hold its fresh linearisation -- so the stage-wise entry
-    # points say so instead of silently doing something else.  synchronous_iteration(robustify=, local_relin=) covers every
-    # combination the reference's own scripts use.
-    def _one_kernel(self, name):
-        raise NotImplementedError(
-            f"BAFactorGraph.{name}() is not available on the device graph: robustify / relinearise / messages / beliefs run as "
-            f"one fused kernel; call synchronous_iteration(robustify=..., local_relin=...) (gbp.py:86-92) instead")
-
+    # The reference lets a caller run the four stages of a sweep one by one (gbp.py:46-84); on the device each is a stage kernel on
+    # the same state (include/gbp_ba.h).  A relinearisation decided by relinearise_factors / compute_all_factors shows in
+    # factor.linpoint / factor.factor at once and enters the messages when they are next computed.
     def robustify_all_factors(self):
-        self._one_kernel('robustify_all_factors')
+        self._flush()
+        self._engine.robustify_all_factors()
+        self._invalidate()
 
     def relinearise_factors(self):
-        self._one_kernel('relinearise_factors')
+        self._flush()
+        self._engine.relinearise_factors()
+        self._invalidate()
 
     def compute_all_messages(self, local_relin=True):
-        self._one_kernel('compute_all_messages')
+        self._flush()
+        self._engine.compute_all_messages(local_relin)
+        self._invalidate()
 
     def compute_all_factors(self):
-        """gbp.py:60-62 relinearises every factor at the current belief means and keeps the messages.  The device stores a
-        message as coefficients in the rows of its factor's Jacobian, so moving the linearisation point without a sweep
-        would change the messages; factors are linearised at the file means by create_ba_graph and at the belief means
-        by the sweep's own relinearisation test."""
-        self._one_kernel('compute_all_factors')
+        self._flush()
+        self._engine.compute_all_factors()
+        self._invalidate()
 
     def joint_distribution_inf(self):
         """gbp.py:94-134: joint (eta, Lambda) over all variables from the priors and the factors at their current

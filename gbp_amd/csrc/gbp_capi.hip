@@ -82,6 +82,7 @@ struct gbp_ba {
     double *d_tmp = nullptr; size_t tmp_bytes = 0;
     std::vector<void *> allocs;
     bool has_beliefs = false;
+    bool pending_possible = false;               // a stage-wise relinearise / compute_factors has run since the messages were last computed
     bool resid_ok = false; double resid[2] = {0.0, 0.0};     // ARE / energy sums of the CURRENT state (ba.py asks for both every sweep)
     // streaming means export (viewer): device staging, two pinned host mirrors, a copy stream
     double *d_mu = nullptr, *h_mu[2] = {nullptr, nullptr};
@@ -288,7 +289,7 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
 // camera-major staging of the general sweep, allocated on first use (F x 27 doubles; the slot -> row map cpos is made by the build)
 static int ensure_staging(gbp_ba *h)
 {
-    if (!h->p.cstage) CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * CSTAGE_ROW));
+    if (!h->p.cstage) CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * h->p.crow));
     if (!h->big_lmks.empty() && !h->d_big) {
         CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
         CHK(upload(h, h->d_big, h->big_lmks));
@@ -358,9 +359,10 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         CHK(ensure_staging(h));
         CHK(launch_factor_stage(h, robustify, local_relin));
         if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
-        if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial);
+        if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial, finish);
         HIPCHK(hipGetLastError());
         if (peer) CHK(launch_peer_push(h, partial, *peer));
+        if (finished) *finished = finish != 0 && h->p.C > 0;
         return GBP_OK;
     }
     CHK(launch_lmk_beliefs(h));                 // update_all_beliefs: from the stored messages
@@ -634,14 +636,14 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         const int n_wg = std::max(1, std::min(T, n_cus));
         const int cgmax = fused_max_cams() + (MAX_CAM_GROUPS - 1) * pass_max_cams();
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
-        const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * CSTAGE_ROW * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
+        const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
                           + (size_t)std::max(C, 1) * (CAMREC + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
                           + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);
         CHK(arena_reserve(h, need));
     }
-    if (general_sweep && F > 0) CHK(dev_alloc(h, &p.cstage, Fz * CSTAGE_ROW));   // out of the same arena (else: on first use, ensure_staging)
+    if (general_sweep && F > 0) CHK(dev_alloc(h, &p.cstage, Fz * p.crow));   // out of the same arena (else: on first use, ensure_staging)
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
     if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
@@ -722,6 +724,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
     p.nstds = d->nstds; p.beta = d->beta; p.eta_damping = d->eta_damping;
     p.num_undamped = d->num_undamped_iters; p.min_linear = d->min_linear_iters; p.loss = d->loss;
     p.robustify = 0; p.local_relin = 1;
+    p.crow = d->num_undamped_iters == 0 ? CSTAGE_ROW : CSTAGE_PLAIN;      // (xtra rows carry the dense remainder too)
     if (d->num_undamped_iters > ITERS_MAX || d->min_linear_iters > ITERS_MAX)
         return fail(GBP_EINVAL, "num_undamped_iters / min_linear_iters above %d are not supported (iters_since_relin saturates there)", ITERS_MAX);
     if (C >= (1 << (32 - META_LMK_BITS))) return fail(GBP_EINVAL, "more than %d cameras are not supported", (1 << (32 - META_LMK_BITS)) - 1);
@@ -899,6 +902,87 @@ int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t loca
     }
     h->has_beliefs = true;
     return GBP_OK;
+}
+
+// ---- the reference's stage-wise entry points (gbp.py:46-84) ------------------------------------------------------------
+// synchronous_iteration is these four in a row (gbp.py:86-92) and runs as one fused kernel; called one by one they run as stage
+// kernels on the same state.  A relinearisation decided by gbp_ba_relinearise / gbp_ba_compute_factors is applied when the
+// messages are next computed (gbp_kernels.hpp, state word header).
+
+int gbp_ba_robustify(gbp_ba_t *h)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    const Params &p = h->p;
+    if (!p.T || p.loss == GBP_LOSS_NONE) return GBP_OK;            // loss None: adaptive variance = gauss_noise_var, nothing stored (gbp.py:302-303)
+    const int nb = grid_for(n_slots(h));
+    if (p.loss == GBP_LOSS_HUBER) hipLaunchKernelGGL(k_stage_robustify<1>, dim3(nb), dim3(BLOCK), 0, h->stream, p);
+    else hipLaunchKernelGGL(k_stage_robustify<2>, dim3(nb), dim3(BLOCK), 0, h->stream, p);
+    HIPCHK(hipGetLastError());
+    return GBP_OK;
+}
+
+static int stage_counts(gbp_ba *h, int out2[2])
+{
+    HIPCHK(hipMemsetAsync(h->d_count, 0, 2 * sizeof(int), h->stream));
+    if (h->p.T) hipLaunchKernelGGL(k_count_pending, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, h->d_count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out2, h->d_count, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GBP_OK;
+}
+
+int gbp_ba_relinearise(gbp_ba_t *h)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    if (!h->has_beliefs) return fail(GBP_ESTATE, "relinearise_factors needs beliefs (call update_all_beliefs first; the reference inverts zero matrices here, gbp.py:73)");
+    if (h->p.T) hipLaunchKernelGGL(k_stage_relinearise, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, 0);
+    HIPCHK(hipGetLastError());
+    h->pending_possible = true;
+    return GBP_OK;
+}
+
+int gbp_ba_compute_factors(gbp_ba_t *h)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    if (!h->has_beliefs) return fail(GBP_ESTATE, "compute_all_factors linearises at the belief means: call update_all_beliefs first");
+    if (!h->p.xtra) {
+        // a factor that moves its linearisation point while its eta damping is on leaves the span its message coefficients live in
+        int c[2];
+        CHK(stage_counts(h, c));
+        if (c[1]) return fail(GBP_ESTATE, "compute_all_factors while %d factors are damped needs the dense message remainder: create the graph with "
+                                           "num_undamped_iters = 0 (or call it before any damping is on)", c[1]);
+    }
+    if (h->p.T) hipLaunchKernelGGL(k_stage_relinearise, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, 1);
+    HIPCHK(hipGetLastError());
+    h->pending_possible = true;
+    return GBP_OK;
+}
+
+int gbp_ba_compute_messages(gbp_ba_t *h, int32_t local_relin)
+{
+    ENTER(h);
+    h->resid_ok = false;
+    if (!h->has_beliefs) return fail(GBP_ESTATE, "compute_all_messages needs beliefs (call update_all_beliefs first)");
+    if (h->pending_possible && !local_relin && !h->p.xtra && h->p.eta_damping != 0.0) {
+        int c[2];
+        CHK(stage_counts(h, c));
+        if (c[0]) return fail(GBP_ESTATE, "compute_all_messages(local_relin=False) damps %d factors in the call that relinearises them: that needs the dense "
+                                           "message remainder (create the graph with num_undamped_iters = 0)", c[0]);
+    }
+    const int slot = (int)(h->sweep_count % RELIN_RING);
+    if (slot % (RELIN_RING / 2) == 0)
+        HIPCHK(hipMemsetAsync(h->d_relin_ring + (size_t)slot * RELIN_LANES, 0, sizeof(int) * (RELIN_RING / 2) * RELIN_LANES, h->stream));
+    h->p.relin_slot = h->d_relin_ring + (size_t)slot * RELIN_LANES;
+    h->sweep_count++;
+    h->p.stage = STAGE_NO_TEST | STAGE_NO_BELIEFS;
+    h->p.reverse_walk = 0;
+    const int rc = launch_factor_stage(h, 0, local_relin);
+    h->p.stage = 0;
+    h->pending_possible = false;
+    return rc;
 }
 
 int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, int32_t local_relin, double *partial_dev)

@@ -76,19 +76,18 @@ struct FusedArgs {
                                 // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results),
                                 // 32 only the first round of the accumulation (same-camera duplicates of a tile dropped)
     unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
-    unsigned long long *clk;    // instrumented runs (gbp_ba_set_kernel_timing): {earliest workgroup start, latest workgroup end} of this
-                                // launch on the device's constant-rate clock (wall_clock64), or NULL.  HIP events around a launch
-                                // also time the dispatch after the event's barrier packet (~5-8 us); this does not.
+    unsigned long long *clk;    // instrumented runs (gbp_ba_set_kernel_timing): where workgroup 0 stores the device's constant-rate clock
+                                // (wall_clock64) when it starts, or NULL.  HIP events around a launch also time the dispatch after the
+                                // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
 };
 
-// first / last thing a workgroup does in an instrumented launch: min over the workgroups of the start, max of the end
-GBP_DEV void clk_begin(unsigned long long *clk) { if (clk && threadIdx.x == 0) atomicMin(clk, (unsigned long long)wall_clock64()); }
-GBP_DEV void clk_end(unsigned long long *clk)
+// Instrumented launches: workgroup 0 stores the clock when it starts (a grid starts first -> last within ~0.5 us).  One plain store:
+// an atomicMin / atomicMax from every workgroup on one word costs ~12 ns each at the memory side -- 500 of them made the reduce
+// launch 3 us longer -- and waiting for a whole workgroup at the end of a short launch cost more still.  Consecutive start stamps
+// tile the stream's timeline the way rocprofv3's kernel durations do.
+GBP_DEV void clk_begin(unsigned long long *clk)
 {
-    if (!clk) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the workgroup's stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)wall_clock64());
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) *clk = (unsigned long long)wall_clock64();
 }
 
 // Phase profile of the persistent loop (tools/phase_profile.py builds the library with -DGBP_PHASE_TIMING): every wave adds
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     }
     GBP_PH(11);                                            // table write-out
     GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
-    clk_end(a.clk);
 }
 
 // More cameras than one LDS table holds (C > 516): the sweep above adds up the messages to the first group of cameras; one
@@ -414,8 +412,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
         r2[0] = make_double2(mu[0], mu[1]); r2[1] = make_double2(mu[2], mu[3]); r2[2] = make_double2(mu[4], mu[5]);
         rec[33] = 0.0;
     }
-    // (no end stamp here: waiting for the whole workgroup at the end of a launch this short -- 500 workgroups that leave one lane
-    //  behind for the 6x6 solve -- made the launch 5 us longer; the next kernel's start stamp closes the interval instead)
 }
 
 // ------------------------------------------------------------------------------------ host --

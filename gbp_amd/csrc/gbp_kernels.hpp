@@ -52,6 +52,8 @@ constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (came
 constexpr int BLOCK = 256;
 constexpr int CSTAGE_ROW = 20;     // doubles per row of the camera-major staging buffer: x0 9 | q_C 2 | W 3 | (xtra: remainder 6)
 constexpr int CSTAGE_USED = 14;    // ... of which the rows carry 14 unless Params::xtra is set
+constexpr int CSTAGE_PLAIN = 16;   // row stride without xtra: one whole, aligned 128-byte line per factor, written in full (a 112-byte row at a
+                                   // 160-byte stride straddled two lines and left both partly written: read-modify-write at the memory side)
 
 struct Params {
     int F, T, L, C;               // factors, tiles (slots = 64 T), landmarks, cameras
@@ -66,13 +68,17 @@ struct Params {
     double *lrec;
     double *cbel, *cprior;
     const int *cptr, *cadj;
-    double *cstage;               // general sweep: [F][CSTAGE_ROW] what rebuilds the camera messages, in camera-major (reference) order, or NULL
+    double *cstage;               // general sweep: [F][crow] what rebuilds the camera messages, in camera-major (reference) order, or NULL
+    int crow;                     // doubles per staged row: CSTAGE_PLAIN, or CSTAGE_ROW with xtra
     const int *cpos;              // slot -> row of cstage
     double *xtra;                 // [slot][9] out-of-span remainder of the message etas, or NULL (gbp_math.hpp header: only when
                                   // num_undamped_iters = 0 lets a factor be damped in the sweep it relinearises in)
     int reverse_walk;             // general sweep: tiles and cameras are visited backwards (every other sweep; results do not depend on it)
     int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
+    int stage;                    // 0: a whole synchronous_iteration.  STAGE_* bits: the reference's stage-wise entry points (gbp.py:46-84)
 };
+constexpr int STAGE_NO_TEST = 1;      // compute_all_messages alone: no relinearisation test, no iters_since_relin bookkeeping (gbp.py:46-54)
+constexpr int STAGE_NO_BELIEFS = 2;   // ... and no belief is touched (the reference updates them in update_all_beliefs only, gbp.py:56-58)
 
 // The sweep's scalar parameters, pinned to SGPRs at the top of every tile: left alone, the compiler copies the ten doubles
 // into VGPR pairs once outside the persistent loop (a VALU instruction takes one scalar operand) and then keeps 20 registers
@@ -89,16 +95,21 @@ GBP_DEV void pin_scalars(Params &q)
 GBP_DEV size_t lin_at(int slot, int row) { return (((size_t)(slot >> 6) * (LIN_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
 GBP_DEV size_t msg_at(int slot, int row) { return (((size_t)(slot >> 6) * (MSG_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
 
-// state word: iters_since_relin << 12 | rank << 2 | robust << 1 | damped.  "rank" (10 bits) is constant per
+// state word: iters_since_relin << 12 | pending << 11 | rank << 2 | robust << 1 | damped.  "rank" (< 64) is constant per
 // factor: its index among the same-camera factors of its tile (fused sweep); every kernel carries it along.
+// "pending": the factor has been told to linearise again at the belief means (relinearise_factors / compute_all_factors called on
+// their own, gbp.py:60-80) but its messages have not been recomputed since.  A message is stored as coefficients in the rows of the
+// Jacobian at the stored linearisation point, so the point moves when the messages are next computed -- at the belief means, which
+// cannot change before that (beliefs are sums of messages) -- and the views show the belief means as the linearisation point meanwhile.
 constexpr int STATE_SHIFT = 12;
 constexpr int ITERS_MAX = (1 << (31 - STATE_SHIFT)) - 1;     // iters_since_relin saturates here (524 287)
-constexpr unsigned STATE_RANK_MASK = 0x3ffu;
+constexpr unsigned STATE_RANK_MASK = 0x1ffu;
+constexpr int STATE_PENDING = 1 << 11;
 GBP_DEV int state_iters(int st) { return st >> STATE_SHIFT; }
 GBP_DEV int state_rank(int st) { return (st >> 2) & (int)STATE_RANK_MASK; }
-GBP_DEV int state_pack(int iters, int rank, bool robust, bool damped)
+GBP_DEV int state_pack(int iters, int rank, bool robust, bool damped, bool pending = false)
 {
-    return (int)(((unsigned)iters << STATE_SHIFT) | ((unsigned)rank << 2) | (robust ? 2u : 0u) | (damped ? 1u : 0u));
+    return (int)(((unsigned)iters << STATE_SHIFT) | (pending ? (unsigned)STATE_PENDING : 0u) | ((unsigned)rank << 2) | (robust ? 2u : 0u) | (damped ? 1u : 0u));
 }
 
 // Per-factor front of FactorGraph.synchronous_iteration (gbp.py:86-92): robustify (gbp.py:296-332), relinearisation
@@ -111,21 +122,28 @@ GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double 
 {
     int iters = state_iters(st);
     bool robust = (st & 2) != 0, damped = (st & 1) != 0;
+    const bool pending = (st & STATE_PENDING) != 0;          // told to relinearise earlier (stage-wise calls): the point moves now
     if (LOSS != 0 && p.robustify) {
         double h0[2];
-        project(x0, p.K, h0);
+        if (pending) {                                       // (its linearisation point is the belief means already: state word header)
+            const double xm[9] = {muC[0], muC[1], muC[2], muC[3], muC[4], muC[5], muL[0], muL[1], muL[2]};
+            project(xm, p.K, h0);
+        } else {
+            project(x0, p.K, h0);
+        }
         avar = robust_variance(LOSS, p.sigma2, p.nstds, z[0] - h0[0], z[1] - h0[1], robust);
     } else if (p.robustify) {
         avar = p.sigma2;                       // loss None: adaptive = gauss_noise_var  gbp.py:302-303
     }
     bool relin = false;
-    if (p.local_relin) {
+    if (p.local_relin && !(p.stage & STAGE_NO_TEST)) {
         double d2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) d2 += (x0[i] - muC[i]) * (x0[i] - muC[i]);
 #pragma unroll
         for (int i = 0; i < 3; ++i) d2 += (x0[6 + i] - muL[i]) * (x0[6 + i] - muL[i]);
-        if (sqrt(d2) > p.beta && iters >= p.min_linear) {
+        // (a pending factor's linearisation point IS the belief means already, as far as the reference can tell: distance 0)
+        if (!pending && sqrt(d2) > p.beta && iters >= p.min_linear) {
             iters = 0;
             damped = false;
             relin = true;
@@ -135,8 +153,9 @@ GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double 
             // never relinearises behaves like the reference's unbounded Python int for ever
             iters = min(iters + 1, ITERS_MAX);
         }
-        if (iters == p.num_undamped) damped = true;      // gbp.py:50-51 (equality, not >=)
     }
+    if (p.local_relin && iters == p.num_undamped) damped = true;      // gbp.py:50-51 (equality, not >=)
+    relin = relin || pending;
     d = p.local_relin ? (damped ? p.eta_damping : 0.0) : p.eta_damping;   // gbp.py:52-54
     st = state_pack(iters, state_rank(st), robust, damped);
     return relin;
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     const int l0 = td.x, nl = td.y, nf = td.z;
     const bool active = lane < nf;
     const int slot = t * WTILE + lane;
-    double srow[XTRA ? CSTAGE_ROW : CSTAGE_USED];           // x0 | q_C | W (| remainder) of this lane's factor AFTER the sweep
+    double srow[XTRA ? CSTAGE_ROW : CSTAGE_PLAIN];          // x0 | q_C | W (| remainder, or two pad doubles) of this lane's factor AFTER the sweep
     if (active) {
         const unsigned meta = p.meta[slot];
         const int cam = (int)(meta >> META_LMK_BITS), lmk = l0 + (int)(meta & ((1u << META_LMK_BITS) - 1u));
@@ -441,6 +460,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
             for (int k = 0; k < 6; ++k) srow[CSTAGE_USED + k] = p.xtra[(size_t)slot * XTRA_ROW + k];
         }
     }
+    if (p.stage & STAGE_NO_BELIEFS) return;                 // compute_all_messages on its own (gbp.py:46-54): whole wave
     // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks: priors | rows into LDS, then nine lanes per landmark
     if (lane < nl) {
         const double *lr = p.lrec + (size_t)(l0 + lane) * LREC;
@@ -453,18 +473,19 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
     // transposed, whole rows go out, 16 bytes per lane
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
-    constexpr int R = XTRA ? CSTAGE_ROW : CSTAGE_USED;
+    constexpr int R = XTRA ? CSTAGE_ROW : CSTAGE_PLAIN;
+    if (!XTRA) { srow[CSTAGE_USED] = 0.0; srow[CSTAGE_USED + 1] = 0.0; }
     if (active) {
 #pragma unroll
         for (int k = 0; k < R; ++k) wl[lane * R + k] = srow[k];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-        constexpr int R2 = R / 2, PER2 = 64 / R2;           // 16 bytes per lane: nine 112-byte rows per instruction (six 160-byte ones)
+        constexpr int R2 = R / 2, PER2 = 64 / R2;           // 16 bytes per lane: eight whole 128-byte lines per instruction (six 160-byte rows with xtra)
         const int g = lane / R2, k = 2 * (lane - g * R2);
         if (g < PER2) {
             for (int f = g; f < nf; f += PER2)
-                *reinterpret_cast<double2 *>(p.cstage + (size_t)wp[f] * CSTAGE_ROW + k) = *reinterpret_cast<const double2 *>(wl + f * R + k);
+                *reinterpret_cast<double2 *>(p.cstage + (size_t)wp[f] * R + k) = *reinterpret_cast<const double2 *>(wl + f * R + k);
         }
     }
 }
@@ -473,16 +494,19 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 // camera, in the reference's adj_factors order): every thread linearises its factors (every 256th of the run), adds their
 // eta = Jc^T q_C (+ remainder) and Lambda = Jc^T W Jc into 27 registers, then the block adds the threads up in a fixed order
 // (shuffle tree, then the four waves) -- bitwise reproducible.
-__global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *__restrict__ partial)
+// finish != 0 (single GPU: nothing to exchange): the camera belief is completed here -- prior + sum, 6x6 solve (gbp.py:182-193) --
+// instead of in a dependent k_cam_finish launch.
+__global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *__restrict__ partial, int finish)
 {
     __shared__ double red[BLOCK / 64][27];
+    __shared__ double tot[27];
     const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
     const int e1 = p.cptr[c + 1];
     for (int e = p.cptr[c] + threadIdx.x; e < e1; e += BLOCK) {
-        const double2 *row = reinterpret_cast<const double2 *>(p.cstage + (size_t)e * CSTAGE_ROW);
+        const double2 *row = reinterpret_cast<const double2 *>(p.cstage + (size_t)e * p.crow);
         double v[CSTAGE_ROW];
 #pragma unroll
         for (int i = 0; i < CSTAGE_USED / 2; ++i) { const double2 t = row[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
@@ -521,6 +545,22 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *
 #pragma unroll
         for (int w = 1; w < BLOCK / 64; ++w) s2 += red[w][threadIdx.x];
         partial[(size_t)c * 27 + threadIdx.x] = s2;
+        tot[threadIdx.x] = s2 + p.cprior[(size_t)c * 27 + threadIdx.x];
+    }
+    if (!finish) return;
+    __syncthreads();
+    double *rec = p.cbel + (size_t)c * CAMREC;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) rec[CAM_ETA + threadIdx.x - 64] = tot[threadIdx.x - 64];
+    if (threadIdx.x == 0) {
+        double eta[6], lam[21], mu[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eta[k] = tot[k];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) lam[k] = tot[6 + k];
+        spd_solve<6>(lam, eta, mu);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
+        rec[33] = 0.0;
     }
 }
 
@@ -624,7 +664,7 @@ struct PeerWait {
     unsigned long long seq;
     long long timeout_ticks;                          // wall_clock64 ticks (100 MHz): a peer that never arrives must not hang the GPU
     int *err;                                         // set to 1 on time-out (reported by gbp_ba_sync)
-    unsigned long long *clk;                          // instrumented runs: {earliest workgroup start, latest end} of the finish launch, or NULL
+    unsigned long long *clk;                          // instrumented runs: where workgroup 0 stores its start time, or NULL
 };
 
 // No fences: a system-scope release / acquire fence on gfx950 writes back / invalidates a whole L2 (8000 waves doing that after the
@@ -665,7 +705,7 @@ __global__ __launch_bounds__(BLOCK) void k_peer_push(const double *__restrict__ 
 constexpr int FINISH_BLOCK = 256;
 __global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const double *gathered, int n_parts, size_t part_stride, PeerWait wait)
 {
-    if (wait.clk && threadIdx.x == 0) atomicMin(wait.clk, (unsigned long long)wall_clock64());
+    if (wait.clk && blockIdx.x == 0 && threadIdx.x == 0) *wait.clk = (unsigned long long)wall_clock64();
     if (wait.flags) {
         if (threadIdx.x < 64) {
             bool ok = true;
@@ -704,18 +744,14 @@ __global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const dou
 #pragma unroll
         for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
         rec[33] = 0.0;
-        if (wait.clk) {                                     // (per camera, not per workgroup: waves leave independently)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicMax(wait.clk + 1, (unsigned long long)wall_clock64());
-        }
     }
 }
 
-// instrumented runs: the stamp ring starts as {max, 0} pairs (atomicMin / atomicMax targets)
+// instrumented runs: the stamp ring starts empty
 __global__ void k_clk_init(unsigned long long *clk, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) clk[i] = (i & 1) ? 0ull : ~0ull;
+    if (i < n) clk[i] = 0ull;
 }
 
 // ----------------------------------------------------------------------------- diagnostics --
@@ -769,6 +805,21 @@ __global__ __launch_bounds__(BLOCK) void k_factor_lambda_max(Params p, double *_
 }
 
 // dense (eta_f 9, Lambda_f 81) of a list of slots for the parity views (Factor.factor gbp.py:230,292)
+// Factor.linpoint as the reference would show it: the stored point, or the belief means for a factor whose relinearisation is pending
+GBP_DEV void effective_linpoint(const Params &p, int slot, double (&x0)[9])
+{
+    int cam, lmk;
+    if ((p.state[slot] & STATE_PENDING) && slot_info(p, slot, cam, lmk)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x0[k] = p.cbel[(size_t)cam * CAMREC + CAM_MU + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x0[6 + k] = p.lrec[(size_t)lmk * LREC + LR_MU + k];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *__restrict__ slots, int n,
                                                           double *__restrict__ eta_out, double *__restrict__ lam_out)
 {
@@ -776,8 +827,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *_
     if (i >= n) return;
     const int slot = slots[i];
     double x0[9], Jc[2][6], Jl[2][3], h[2], J[2][9], rho[2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+    effective_linpoint(p, slot, x0);
     linearise(x0, p.K, Jc, Jl, h);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -811,8 +861,10 @@ __global__ __launch_bounds__(BLOCK) void k_export_lin(Params p, const int *__res
     if (i >= n) return;
     const int slot = slots[i];
     if (x0_out) {
+        double x0[9];
+        effective_linpoint(p, slot, x0);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) x0_out[(size_t)i * 9 + k] = p.lin[lin_at(slot, ROW_X0 + k)];
+        for (int k = 0; k < 9; ++k) x0_out[(size_t)i * 9 + k] = x0[k];
     }
     if (z_out) { z_out[(size_t)i * 2] = p.lin[lin_at(slot, ROW_Z)]; z_out[(size_t)i * 2 + 1] = p.lin[lin_at(slot, ROW_Z + 1)]; }
 }
@@ -855,6 +907,65 @@ __global__ __launch_bounds__(BLOCK) void k_count_relin(Params p, int *__restrict
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) s += red[w];
         if (s) atomicAdd(out, s);
+    }
+}
+
+// ---------------------------------------------------------------- stage-wise entry points --
+// The reference lets a caller run the stages of a sweep one by one (gbp.py:46-84).  robustify and the relinearisation DECISION
+// are state-word / variance updates; the relinearisation itself is deferred to the next message computation (state word header).
+
+// FactorGraph.robustify_all_factors (gbp.py:82-84 -> Factor.robustify_loss gbp.py:296-332): the adaptive variance and the robust
+// flag from the residual at the linearisation point; eta_f / Lambda_f are rebuilt from (x0, z, variance) wherever they are needed.
+template <int LOSS>
+__global__ __launch_bounds__(BLOCK) void k_stage_robustify(Params p)
+{
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    int cam, lmk;
+    if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
+    double x0[9], h0[2];
+    effective_linpoint(p, slot, x0);
+    project(x0, p.K, h0);
+    int st = p.state[slot];
+    bool robust = (st & 2) != 0;
+    const double avar = robust_variance(LOSS, p.sigma2, p.nstds, p.lin[lin_at(slot, ROW_Z)] - h0[0], p.lin[lin_at(slot, ROW_Z + 1)] - h0[1], robust);
+    p.lin[lin_at(slot, ROW_AVAR)] = avar;
+    p.state[slot] = (st & ~2) | (robust ? 2 : 0);
+}
+
+// FactorGraph.relinearise_factors (gbp.py:64-80), or with mark_all FactorGraph.compute_all_factors (gbp.py:60-62: every factor,
+// counters and damping untouched): the decision and its bookkeeping; the move itself is deferred (STATE_PENDING).
+__global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_all)
+{
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    int cam, lmk;
+    if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
+    int st = p.state[slot];
+    if (mark_all) { p.state[slot] = st | STATE_PENDING; return; }
+    int iters = state_iters(st);
+    bool damped = (st & 1) != 0, pending = (st & STATE_PENDING) != 0;
+    double d2 = 0.0;
+    if (!pending) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double d = p.lin[lin_at(slot, ROW_X0 + k)] - p.cbel[(size_t)cam * CAMREC + CAM_MU + k]; d2 += d * d; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double d = p.lin[lin_at(slot, ROW_X0 + 6 + k)] - p.lrec[(size_t)lmk * LREC + LR_MU + k]; d2 += d * d; }
+    }
+    if (!pending && sqrt(d2) > p.beta && iters >= p.min_linear) { iters = 0; damped = false; pending = true; }
+    else iters = min(iters + 1, ITERS_MAX);
+    p.state[slot] = state_pack(iters, state_rank(st), (st & 2) != 0, damped, pending);
+}
+
+// {factors with a pending relinearisation, factors that are damped}: what decides whether a deferred relinearisation is exact
+__global__ __launch_bounds__(BLOCK) void k_count_pending(Params p, int *__restrict__ out2)
+{
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    int cam, lmk;
+    const bool live = slot < p.T * WTILE && slot_info(p, slot, cam, lmk);
+    const int st = live ? p.state[slot] : 0;
+    const unsigned long long a = __ballot(live && (st & STATE_PENDING)), b = __ballot(live && (st & 1));
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(out2, __popcll(a));
+        if (b) atomicAdd(out2 + 1, __popcll(b));
     }
 }
 

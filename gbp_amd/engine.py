@@ -147,6 +147,19 @@ class BAEngine:
     def iterate(self, n, robustify=True, local_relin=True):
         check(self._lib.gbp_ba_iterate(self._h, int(n), int(bool(robustify)), int(bool(local_relin))))
 
+    # the same sweep stage by stage (gbp.py:46-84); synchronous_iteration is the fused form of these four in a row
+    def robustify_all_factors(self):
+        check(self._lib.gbp_ba_robustify(self._h))
+
+    def relinearise_factors(self):
+        check(self._lib.gbp_ba_relinearise(self._h))
+
+    def compute_all_messages(self, local_relin=True):
+        check(self._lib.gbp_ba_compute_messages(self._h, int(bool(local_relin))))
+
+    def compute_all_factors(self):
+        check(self._lib.gbp_ba_compute_factors(self._h))
+
     def sync(self):
         check(self._lib.gbp_ba_sync(self._h))
 

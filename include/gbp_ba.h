@@ -91,6 +91,18 @@ int gbp_ba_update_beliefs(gbp_ba_t *h);                                 /* Facto
 int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin);
                                                                         /* n x FactorGraph.synchronous_iteration gbp.py:86-92 */
 
+/* the same sweep stage by stage (the reference's FactorGraph exposes all four; synchronous_iteration = robustify ->
+ * relinearise -> compute_messages -> update_beliefs, gbp.py:86-92, and that fixed sequence is what gbp_ba_iterate fuses).  A
+ * relinearisation decided by gbp_ba_relinearise / gbp_ba_compute_factors takes effect on the messages when they are next
+ * computed; the views (gbp_ba_get_factors) show the new linearisation point at once.  gbp_ba_compute_factors with damped factors,
+ * and gbp_ba_compute_messages(local_relin = 0) with pending relinearisations, need a graph created with num_undamped_iters = 0
+ * (GBP_ESTATE otherwise: a damped message of a factor that has just moved its linearisation point is not in the span the
+ * compact message storage covers). */
+int gbp_ba_robustify(gbp_ba_t *h);                                      /* FactorGraph.robustify_all_factors gbp.py:82-84 */
+int gbp_ba_relinearise(gbp_ba_t *h);                                    /* FactorGraph.relinearise_factors gbp.py:64-80 */
+int gbp_ba_compute_messages(gbp_ba_t *h, int32_t local_relin);          /* FactorGraph.compute_all_messages gbp.py:46-54 (no belief changes) */
+int gbp_ba_compute_factors(gbp_ba_t *h);                                /* FactorGraph.compute_all_factors gbp.py:60-62 */
+
 /* diagnostics ba.py prints every iteration */
 int gbp_ba_are(gbp_ba_t *h, double *out);                               /* BAFactorGraph.are gbp_ba.py:61-69 */
 int gbp_ba_energy(gbp_ba_t *h, double *out);                            /* FactorGraph.energy gbp.py:36-44 */
@@ -199,12 +211,11 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h);
 int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable);
 int gbp_ba_get_kernel_timing(gbp_ba_t *h, double *total_ms, int32_t *n_launches, const char **kernel_name);
 /* the same instrumented run also stamps, inside the kernels, the device's constant-rate clock (wall_clock64): per sweep since
- * gbp_ba_set_kernel_timing six stamps in MICROSECONDS since the first one -- {fused sweep: earliest workgroup start, latest
- * workgroup end; camera reduce: start, (unused); camera finish (sharded only): start, end}; NaN where a kernel did not run or
- * does not stamp.  Consecutive START stamps tile the stream's timeline the way rocprofv3's kernel durations do (a kernel's
- * interval then includes its own drain and the next dispatch).  HIP
- * events around a launch include the dispatch latency behind the event's barrier packet (5-8 us); the stamps do not, and
- * they do not serialise the stream.  Up to 4096 sweeps per enable. */
+ * gbp_ba_set_kernel_timing six slots in MICROSECONDS since the first stamp, of which three are used -- [0] fused sweep, [2]
+ * camera reduce, [4] camera finish (sharded only): when the kernel's workgroup 0 started; NaN where a kernel did not run.
+ * Consecutive START stamps tile the stream's timeline the way rocprofv3's kernel durations do (a kernel's interval includes
+ * its own drain and the next dispatch).  HIP events around a launch add the dispatch latency behind the event's barrier
+ * packet (5-8 us) and serialise the stream; the stamps are one store per launch.  Up to 4096 sweeps per enable. */
 int gbp_ba_get_sweep_clocks(gbp_ba_t *h, double *us6, int32_t cap_sweeps, int32_t *n_sweeps);
 /* which exchange the sharded loop uses and what it says about itself: kind GBP_COMM_*, this rank, the rank count (for RCCL:
  * ncclCommCount of the library's communicator) */

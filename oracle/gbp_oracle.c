@@ -510,6 +510,17 @@ void gbpo_relinearise(gbpo_t *g)                                 /* gbp/gbp.py:6
     for (int f = 0; f < g->F; ++f) relinearise_one(g, f);
 }
 
+void gbpo_compute_factors(gbpo_t *g)                             /* gbp/gbp.py:60-62: Factor.compute_factor() with no linpoint = the
+                                                                    adjacent belief means (gbp.py:273-277), every factor; nothing else changes */
+{
+#pragma omp parallel for schedule(static) num_threads(g->nthreads)
+    for (int f = 0; f < g->F; ++f) {
+        double m[9];
+        adj_means(g, f, m);
+        compute_factor(g, f, m);
+    }
+}
+
 void gbpo_compute_messages(gbpo_t *g, int local_relin)           /* gbp/gbp.py:46-54 */
 {
 #pragma omp parallel for schedule(static) num_threads(g->nthreads)

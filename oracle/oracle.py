@@ -47,6 +47,7 @@ def lib():
         L.gbpo_robustify.argtypes = [ct.c_void_p]
         L.gbpo_relinearise.argtypes = [ct.c_void_p]
         L.gbpo_compute_messages.argtypes = [ct.c_void_p, ct.c_int]
+        L.gbpo_compute_factors.argtypes = [ct.c_void_p]
         L.gbpo_iterate.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int]
         L.gbpo_are.restype = ct.c_double
         L.gbpo_are.argtypes = [ct.c_void_p]
@@ -137,6 +138,19 @@ class OracleBA:
 
     def synchronous_iteration(self, local_relin=True, robustify=False):
         lib().gbpo_iterate(self._h, 1, int(robustify), int(local_relin))
+
+    # the stages one by one (gbp.py:46-84)
+    def robustify_all_factors(self):
+        lib().gbpo_robustify(self._h)
+
+    def relinearise_factors(self):
+        lib().gbpo_relinearise(self._h)
+
+    def compute_all_messages(self, local_relin=True):
+        lib().gbpo_compute_messages(self._h, int(bool(local_relin)))
+
+    def compute_all_factors(self):
+        lib().gbpo_compute_factors(self._h)
 
     def iterate(self, n, robustify=True, local_relin=True):
         lib().gbpo_iterate(self._h, int(n), int(robustify), int(local_relin))

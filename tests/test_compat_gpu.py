@@ -67,7 +67,7 @@ def test_ba_script_sequence(compat_path):
 def test_factor_graph_surface_of_the_device_graph(compat_path):
     """What scripts written against gbp.FactorGraph may touch beyond ba.py's own sequence: var_nodes is always
     a sequence, priors can be assigned through the node views, the batch joint is available, and the stage-wise methods
-    that one fused kernel cannot honour say so."""
+    (gbp.py:46-84) exist on the device graph too."""
     from gbp import gbp_ba
     configs = dict(gauss_noise_std=2, loss=None, Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8,
                    eta_damping=0.4, prior_std_weaker_factor=50.0)
@@ -107,9 +107,11 @@ def test_factor_graph_surface_of_the_device_graph(compat_path):
     assert np.allclose(lam[a:a + 6, a:a + 6], blk + graph.cam_nodes[f7.adj_vIDs[0]].prior.lam, rtol=1e-10)
     mu, sigma = graph.joint_distribution_cov()
     assert np.isfinite(mu).all() and mu.shape == eta.shape
-    for name in ('robustify_all_factors', 'relinearise_factors', 'compute_all_messages', 'compute_all_factors'):
-        with pytest.raises(NotImplementedError):
-            getattr(graph, name)()
+    # the four stages one by one = synchronous_iteration (gbp.py:86-92); the full stage-wise parity is tests/test_stagewise_gpu.py
+    graph.robustify_all_factors()
+    graph.relinearise_factors()
+    graph.compute_all_messages(local_relin=True)
+    graph.update_all_beliefs()
     graph.synchronous_iteration(robustify=True, local_relin=True)
     assert graph.count_relinearising() == sum(1 for f in graph.factors if f.iters_since_relin == 0)
     assert np.array_equal(graph.factors[3].linpoint, graph._engine.factors(3, 1, dense=False)['linpoint'][0])

@@ -1,0 +1,177 @@
+"""The reference's stage-wise FactorGraph methods on the DEVICE graph (gbp/gbp.py:46-84: robustify_all_factors, relinearise_factors,
+compute_all_messages, compute_all_factors, update_all_beliefs), stage by stage against the C oracle, which runs them as separate
+passes over dense per-factor state exactly like the reference.  After every single call: factor potentials (eta_f, Lambda_f),
+linearisation points, adaptive variances / robust flags, iters_since_relin, eta_damping, both messages and all beliefs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, rel_err_rows
+from gbp_amd.balio import read_bal
+from gbp_amd.synthetic import make_synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(e, o, tag, belief_tol=1e-6, msg_tol=1e-5):
+    fe, fo = e.factors(), o.factors()
+    # (a relinearised factor's point is a belief mean, i.e. the solution of a 6x6 / 3x3 system: it inherits the belief tolerance)
+    assert np.allclose(fe['linpoint'], fo['linpoint'], rtol=1e-6, atol=1e-6), (tag, np.abs(fe['linpoint'] - fo['linpoint']).max())
+    assert rel_err_rows(fe['eta'], fo['eta']) < 1e-5 and rel_err_rows(fe['lam'], fo['lam']) < 1e-5, tag
+    se, so = e.relin_state(), o.relin_state()
+    assert np.array_equal(se['iters_since_relin'], so['iters_since_relin']), tag
+    assert np.array_equal(se['eta_damping'], so['eta_damping']), tag
+    assert np.array_equal(se['robust_flag'], so['robust_flag']), tag
+    assert np.allclose(se['adaptive_var'], so['adaptive_var'], rtol=1e-8), tag
+    for a, b in zip(e.messages(), o.messages()):
+        assert rel_err_rows(a, b) < msg_tol, tag
+    assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())) < belief_tol, tag
+
+
+def pair(eng, oracle_mod, p, **cfg):
+    o = oracle_mod.OracleBA.from_problem(p, threads=4, **cfg)
+    e = eng.BAEngine.from_problem(p, **cfg)
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+    return o, e
+
+
+@pytest.mark.parametrize('loss', [None, 'huber', 'constant'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_stages_one_by_one_equal_the_reference_order(oracle_mod, loss, fused):
+    """robustify -> relinearise -> messages -> beliefs over ba.py's own 26-sweep schedule on fr1desk_vsmall (iters_since_relin reset
+    to 1 before sweeps 3 and 8, ba.py:91-93, so that the graph has settled before the first relinearisation at sweep 15 and the
+    damping switch six sweeps later); every intermediate state is compared, then the next stage continues from it.  Every third
+    sweep runs the fused synchronous_iteration instead, so stage-wise and fused sweeps interleave on one state.  (Without the
+    resets, or with shorter intervals, GBP itself diverges on this data -- tools/debug_stage.py -- and nothing can be compared.)"""
+    from gbp_amd import engine as eng
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    o, e = pair(eng, oracle_mod, p, loss=loss, Nstds=3.0)
+    if not fused:
+        e.close()
+        e = eng.BAEngine.from_problem(p, loss=loss, Nstds=3.0, fused=False)
+        e.generate_priors_var(50.0)
+        e.update_all_beliefs()
+    n_relin, stage_relin, saw_damping = 0, 0, False
+    for i in range(26):
+        if i in (3, 8):
+            for g in (o, e):
+                g.set_iters_since_relin(1)
+        if i % 3 == 2:
+            for g in (o, e):
+                g.synchronous_iteration(robustify=True, local_relin=True)
+            n_relin += int((o.relin_state()['iters_since_relin'] == 0).sum())
+            compare(e, o, (i, 'fused sweep'))
+            continue
+        for g in (o, e):
+            g.robustify_all_factors()
+        compare(e, o, (i, 'robustify'))
+        for g in (o, e):
+            g.relinearise_factors()
+        k = int((o.relin_state()['iters_since_relin'] == 0).sum())
+        n_relin += k
+        stage_relin += k
+        compare(e, o, (i, 'relinearise'))
+        for g in (o, e):
+            g.compute_all_messages(local_relin=True)
+        compare(e, o, (i, 'messages'))
+        saw_damping = saw_damping or bool((o.relin_state()['eta_damping'] > 0).any())
+        for g in (o, e):
+            g.update_all_beliefs()
+        compare(e, o, (i, 'beliefs'))
+    assert stage_relin > 100, (n_relin, stage_relin)       # the deferred relinearisation was really exercised
+    assert saw_damping                                     # ... and so was the damping switch of compute_all_messages
+
+
+def settled_pair(eng, oracle_mod, **cfg):
+    """fr1desk_vsmall after ba.py's first 16 sweeps: past the first relinearisation, well conditioned."""
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    o, e = pair(eng, oracle_mod, p, **cfg)
+    for g in (o, e):
+        oracle_mod.replay_ba(g, 16)
+    return o, e
+
+
+def test_odd_call_orders(oracle_mod):
+    """Orders no script of the reference uses but its API allows: two relinearise calls in a row (the second one sees factors that
+    sit at the belief means), robustify after relinearise (the residual is taken at the NEW point), update_all_beliefs between
+    relinearise and messages, messages twice, compute_all_messages(local_relin=False) with nothing pending."""
+    from gbp_amd import engine as eng
+    o, e = settled_pair(eng, oracle_mod, loss='huber', Nstds=3.0)
+    for g in (o, e):
+        g.set_iters_since_relin(8)                         # everybody may relinearise at the next test
+    compare(e, o, 'start')
+    steps = ['relinearise_factors', 'relinearise_factors', 'robustify_all_factors', 'update_all_beliefs', 'compute_all_messages',
+             'compute_all_messages', 'update_all_beliefs', 'relinearise_factors', 'compute_all_messages', 'update_all_beliefs']
+    for k, name in enumerate(steps):
+        for g in (o, e):
+            getattr(g, name)()
+        if k == 0:
+            assert (o.relin_state()['iters_since_relin'] == 0).sum() > 100
+        compare(e, o, (k, name))
+    for g in (o, e):
+        g.compute_all_messages(local_relin=False)
+        g.update_all_beliefs()
+    compare(e, o, 'global damping')
+
+
+def test_second_relinearise_with_min_linear_zero(oracle_mod):
+    """min_linear_iters = 0: a factor may relinearise at every call, so a second relinearise_factors() in a row meets factors whose
+    relinearisation is still pending -- for the reference they sit at the belief means (distance 0 < beta) and only count up."""
+    from gbp_amd import engine as eng
+    p = make_synthetic(n_cams=12, n_lmks=300, obs_per_lmk=5, seed=3)
+    o, e = pair(eng, oracle_mod, p, min_linear_iters=0, num_undamped_iters=2)
+    for g in (o, e):
+        g.synchronous_iteration(robustify=True, local_relin=True)
+    for name in ('relinearise_factors', 'relinearise_factors', 'compute_all_messages', 'update_all_beliefs', 'relinearise_factors',
+                 'compute_all_messages', 'update_all_beliefs'):
+        for g in (o, e):
+            getattr(g, name)()
+        compare(e, o, name)
+    assert (o.relin_state()['iters_since_relin'] <= 1).all()
+
+
+def test_compute_all_factors(oracle_mod):
+    """gbp.py:60-62: every factor linearised again at the belief means, counters and damping untouched -- exact on the compact message
+    storage while no factor is damped, refused (GBP_ESTATE) once one is, and exact again on a graph that carries the dense message
+    remainder (num_undamped_iters = 0)."""
+    from gbp_amd import engine as eng
+    from gbp_amd._capi import GbpError
+    o, e = settled_pair(eng, oracle_mod)                   # sweep 15 relinearised everybody: nobody is damped at sweep 16
+    assert not (o.relin_state()['eta_damping'] > 0).any()
+    for g in (o, e):
+        g.compute_all_factors()
+    compare(e, o, 'after compute_all_factors')             # the views show the new linearisation at once
+    for g in (o, e):
+        g.compute_all_messages()
+        g.update_all_beliefs()
+    compare(e, o, 'messages after compute_all_factors')
+    for g in (o, e):
+        g.iterate(6)
+    compare(e, o, 'six more sweeps')
+    assert (o.relin_state()['eta_damping'] > 0).any()
+    with pytest.raises(GbpError) as ei:
+        e.compute_all_factors()
+    assert ei.value.code == -5
+    p = make_synthetic(n_cams=12, n_lmks=300, obs_per_lmk=5, seed=3)
+    o2, e2 = pair(eng, oracle_mod, p, num_undamped_iters=0, min_linear_iters=4, eta_damping=0.4)
+    for g in (o2, e2):
+        g.iterate(3)
+        g.compute_all_factors()
+        g.compute_all_messages()
+        g.update_all_beliefs()
+        g.iterate(2)
+    assert (o2.relin_state()['eta_damping'] > 0).all()     # damped throughout: the relinearised messages carry a dense remainder
+    compare(e2, o2, 'dense remainder')
+
+
+def test_stagewise_needs_beliefs():
+    from gbp_amd import engine as eng
+    from gbp_amd._capi import GbpError
+    p = make_synthetic(n_cams=4, n_lmks=30, obs_per_lmk=3, seed=1)
+    e = eng.BAEngine.from_problem(p)
+    for name in ('relinearise_factors', 'compute_all_messages', 'compute_all_factors'):
+        with pytest.raises(GbpError):
+            getattr(e, name)()
