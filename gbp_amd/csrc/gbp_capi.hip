@@ -123,7 +123,7 @@ struct gbp_ba {
         int n_ranks = 0, rank = 0; bool connected = false;
         void *base[MAX_PEERS] = {}; bool opened[MAX_PEERS] = {};
         unsigned long long seq = 0;
-        int *d_ctl = nullptr;                    // {arrived, err}
+        int *d_ctl = nullptr;                    // {unused, err}: a finish wave that gave up waiting sets err
         long long timeout_ticks = 0;
     } peer;
     hipStream_t side_stream = nullptr;           // beliefs of over-sized landmarks run beside the exchange
@@ -310,8 +310,8 @@ static int launch_big_lmk_beliefs(gbp_ba *h, hipStream_t stream)
 // general sweep / update_all_beliefs under the peer-store exchange: the finished partial sums go into every rank's mailbox
 static int launch_peer_push(gbp_ba *h, const double *partial, const PeerOut &peer)
 {
-    const int n = h->p.C * 27;
-    hipLaunchKernelGGL(k_peer_push, dim3(std::max(1, grid_for((size_t)n))), dim3(BLOCK), 0, h->stream, partial, n, peer);
+    if (!h->p.C) return GBP_OK;
+    hipLaunchKernelGGL(k_peer_push, dim3((h->p.C + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, h->stream, partial, h->p.C, peer);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }
@@ -319,7 +319,7 @@ static int launch_peer_push(gbp_ba *h, const double *partial, const PeerOut &pee
 // defer_big: leave the beliefs of the over-sized landmarks (k_lmk_belief_list) to the caller, who runs them beside the
 // camera exchange (launch_big_lmk_beliefs)
 static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish = 0,
-                       bool *finished = nullptr, bool defer_big = false, const PeerOut *peer = nullptr)
+                       bool *finished = nullptr, bool defer_big = false, const PeerOut *peer = nullptr, const PeerWait *merged = nullptr)
 {
     if (finished) *finished = false;
     h->clk_cur = (h->timing && h->d_clk && h->clk_used < CLK_RING) ? h->d_clk + 6 * (size_t)h->clk_used++ : nullptr;
@@ -345,9 +345,10 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         static const bool no_rev = getenv("GBP_NO_REVERSE") != nullptr;
         const int reverse = no_rev ? 0 : (int)(h->walk_parity & 1u);
         h->walk_parity ^= 1u;
-        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse, peer, h->clk_cur);
+        int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse, peer, h->clk_cur, merged);
+        if (merged && peer && finished) *finished = true;
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (finished) *finished = finish != 0;
+        if (finished && !(merged && peer)) *finished = finish != 0;
         return GBP_OK;
     }
     if (with_messages) {
@@ -426,17 +427,12 @@ int rccl_exchange(void *ctx, const double *send_dev, double *recv_dev, uint64_t 
 }
 }  // namespace
 
-// mailbox geometry: data [2][n_ranks][C27] doubles, then arrival words [2][n_ranks][PEER_FLAG_STRIDE]
-static inline size_t peer_c27(const gbp_ba *h) { return (size_t)std::max(h->p.C, 1) * 27; }
-static inline size_t peer_flag_offset(const gbp_ba *h, int n) { return ((2 * (size_t)n * peer_c27(h) * sizeof(double) + 127) / 128) * 128; }
-static inline size_t peer_bytes(const gbp_ba *h, int n) { return peer_flag_offset(h, n) + 2 * (size_t)n * PEER_FLAG_STRIDE * sizeof(unsigned long long); }
+// mailbox geometry: [2 halves][n_ranks][C] rows of PEER_ROW doubles (27 sums | tag)
+static inline size_t peer_block(const gbp_ba *h) { return (size_t)std::max(h->p.C, 1) * PEER_ROW; }
+static inline size_t peer_bytes(const gbp_ba *h, int n) { return 2 * (size_t)n * peer_block(h) * sizeof(double); }
 static inline double *peer_data(const gbp_ba *h, void *base, int n, int half, int src)
 {
-    return static_cast<double *>(base) + ((size_t)half * n + src) * peer_c27(h);
-}
-static inline unsigned long long *peer_flag(const gbp_ba *h, void *base, int n, int half, int src)
-{
-    return reinterpret_cast<unsigned long long *>(static_cast<char *>(base) + peer_flag_offset(h, n)) + ((size_t)half * n + src) * PEER_FLAG_STRIDE;
+    return static_cast<double *>(base) + ((size_t)half * n + src) * peer_block(h);
 }
 
 static void peer_release(gbp_ba *h)
@@ -1067,7 +1063,7 @@ int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t fla
     if (pe.mailbox) { HIPCHK(hipFree(pe.mailbox)); pe.mailbox = nullptr; }
     const size_t bytes = peer_bytes(h, n_ranks);
     // fine-grained (uncached across devices) when the runtime grants it: peers store into it over xGMI while this rank polls it
-    pe.finegrained = hipExtMallocWithFlags(&pe.mailbox, bytes, hipDeviceMallocFinegrained) == hipSuccess;
+    pe.finegrained = !getenv("GBP_PEER_COARSE") && hipExtMallocWithFlags(&pe.mailbox, bytes, hipDeviceMallocFinegrained) == hipSuccess;
     if (!pe.finegrained) { (void)hipGetLastError(); HIPCHK(hipMalloc(&pe.mailbox, bytes)); }
     HIPCHK(hipMemsetAsync(pe.mailbox, 0, bytes, h->stream));
     if (!pe.d_ctl) HIPCHK(hipMalloc(reinterpret_cast<void **>(&pe.d_ctl), 2 * sizeof(int)));
@@ -1128,13 +1124,15 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
     gbp_ba::Peer &pe = h->peer;
     const int n = pe.n_ranks, half = (int)(++pe.seq & 1ull);
     PeerOut po{};
-    po.n = n; po.seq = pe.seq; po.arrived = pe.d_ctl;
-    for (int r = 0; r < n; ++r) {
-        po.dst[r] = peer_data(h, pe.base[r], n, half, pe.rank);
-        po.flag[r] = peer_flag(h, pe.base[r], n, half, pe.rank);
-    }
+    po.n = n; po.seq = pe.seq;
+    for (int r = 0; r < n; ++r) po.dst[r] = peer_data(h, pe.base[r], n, half, pe.rank);
+    PeerWait w{peer_data(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1, nullptr};
     const bool big = with_messages && !h->big_lmks.empty();
-    CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, nullptr, big, &po));
+    // Without a rendezvous hook everything behind the fused sweep is ONE launch (k_cam_reduce_xchg); logical ranks on one device
+    // (the hook is set) keep reduce / push and finish apart, with the hook between them, so that they never spin on each other.
+    const bool merged = !h->xch_fn && with_messages && h->fused.enabled && !getenv("GBP_PEER_SPLIT");
+    bool finished = false;
+    CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, &finished, big, &po, merged ? &w : nullptr));
     if (big) {
         if (!h->side_stream) {
             HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
@@ -1146,12 +1144,13 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
         CHK(launch_big_lmk_beliefs(h, h->side_stream));
         HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
     }
-    if (h->xch_fn) {                                         // optional rendezvous hook (logical ranks on ONE device: tests)
-        int rc = h->xch_fn(h->xch_ctx, nullptr, nullptr, 0, h->stream);
-        if (rc != GBP_OK) return rc < 0 ? rc : fail(GBP_EHIP, "the rendezvous function returned %d", rc);
+    if (!finished) {
+        if (h->xch_fn) {                                     // rendezvous hook (logical ranks on ONE device: tests)
+            int rc = h->xch_fn(h->xch_ctx, nullptr, nullptr, 0, h->stream);
+            if (rc != GBP_OK) return rc < 0 ? rc : fail(GBP_EHIP, "the rendezvous function returned %d", rc);
+        }
+        CHK(launch_cam_finish(h, nullptr, n, 0, &w));
     }
-    PeerWait w{peer_flag(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1, nullptr};
-    CHK(launch_cam_finish(h, peer_data(h, pe.mailbox, n, half, 0), n, peer_c27(h), &w));
     if (big) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return GBP_OK;
 }

@@ -388,15 +388,15 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
         red[part * 27 + k] = s;
     }
     __syncthreads();
+    double s = 0.0;
     if (tid < 27) {
-        double s = red[tid];
+        s = red[tid];
 #pragma unroll
         for (int q = 1; q < RED_PARTS; ++q) s += red[q * 27 + tid];
         partial[(size_t)c * 27 + tid] = s;
-        for (int r = 0; r < peer.n; ++r) peer_store(peer.dst[r] + (size_t)c * 27 + tid, s);      // sharded, peer-store exchange: straight into every rank's mailbox
         tot[tid] = s + p.cprior[(size_t)c * 27 + tid];
     }
-    if (peer.n) peer_arrive(peer);
+    if (peer.n && tid < 64) peer_push_row(peer, c, s, tid);   // sharded, peer-store exchange: straight into every rank's mailbox
     if (!finish) return;
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
@@ -412,6 +412,55 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
         r2[0] = make_double2(mu[0], mu[1]); r2[1] = make_double2(mu[2], mu[3]); r2[2] = make_double2(mu[4], mu[5]);
         rec[33] = 0.0;
     }
+}
+
+// Sharded sweep with the peer-store exchange, everything after the sweep kernel in ONE launch: a small grid of persistent
+// workgroups first reduces and PUSHES all of its cameras (workgroup tables -> 27 sums -> row c of every rank's mailbox + tag),
+// then finishes them, one wave per camera: wait for the n_ranks tags of row c, add the parts in rank order, prior, 6x6 solve.
+// Every workgroup of every rank pushes before it waits, and the grid is never larger than what is resident at once (XCHG_BLOCKS = two
+// 1024-thread workgroups per CU of an MI355X; one camera per workgroup up to 512 cameras, several beyond), so ranks cannot wait for
+// each other in a cycle.  Against reduce -> finish as two launches
+// this saves a kernel boundary and the global "all rows are out" hand-off; against RCCL also the collective's launch and sync.
+constexpr int XCHG_BLOCKS = 512;
+__global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
+                                                                 double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][28] | red[RED_PARTS][27]
+    const int n = n_blocks * TROW, tid = threadIdx.x;
+    double *red = sh + ((n + 1) & ~1);
+    clk_begin(clk);
+    for (int c = blockIdx.x; c < p.C; c += gridDim.x) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(block_partials + (size_t)c * n);      // (TROW is even: 16-byte aligned)
+        const int n2 = n / 2;
+        for (int i0 = tid; i0 < n2; i0 += 4 * RED_THREADS) {
+            double2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = i0 + j * RED_THREADS; v[j] = i < n2 ? s2[i] : make_double2(0.0, 0.0); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = i0 + j * RED_THREADS; if (i < n2) { sh[2 * i] = v[j].x; sh[2 * i + 1] = v[j].y; } }
+        }
+        __syncthreads();
+        if (tid < RED_PARTS * 27) {
+            const int part = tid / 27, k = tid - part * 27;
+            double s = 0.0;
+            for (int b = part; b < n_blocks; b += RED_PARTS) s += sh[b * TROW + k];
+            red[part * 27 + k] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double s = 0.0;
+            if (tid < 27) {
+                s = red[tid];
+#pragma unroll
+                for (int q = 1; q < RED_PARTS; ++q) s += red[q * 27 + tid];      // the same order as k_cam_reduce_tree: bitwise the same sums
+                partial[(size_t)c * 27 + tid] = s;
+            }
+            peer_push_row(peer, c, s, tid);
+        }
+        __syncthreads();                                     // sh is overwritten by the next camera
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int c = blockIdx.x + wave * gridDim.x; c < p.C; c += (RED_THREADS / 64) * gridDim.x) cam_finish_wave(p, nullptr, peer.n, 0, wait, c, lane);
 }
 
 // ------------------------------------------------------------------------------------ host --
@@ -512,6 +561,8 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 #undef GBP_SET_SHMEM
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_xchg), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
     pl.enabled = true;
     return 0;
 }
@@ -519,7 +570,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 // returns 0 or a hipError_t value
 inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int local_relin, double *partial, hipStream_t stream,
                         int finish, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool defer_big = false, int reverse = 0,
-                        const PeerOut *peer = nullptr, unsigned long long *clk = nullptr)
+                        const PeerOut *peer = nullptr, unsigned long long *clk = nullptr, const PeerWait *merged = nullptr)
 {
     pl.args.reverse = reverse;
     pl.args.clk = clk;                                      // [0..1] the sweep kernel's stamps, [2..3] the reduce kernel's
@@ -544,6 +595,12 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     const size_t red_shmem = sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27);
     PeerOut po{};
     if (peer) po = *peer;
+    if (merged && peer) {                                   // reduce -> push -> wait -> finish in one launch (peer-store exchange)
+        static const int xb = getenv("GBP_XCHG_BLOCKS") ? std::max(1, atoi(getenv("GBP_XCHG_BLOCKS"))) : XCHG_BLOCKS;
+        hipLaunchKernelGGL(k_cam_reduce_xchg, dim3(std::min(p.C, xb)), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial,
+                           po, *merged, clk ? clk + 2 : nullptr);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po, clk ? clk + 2 : nullptr);
     return (int)hipGetLastError();
 }

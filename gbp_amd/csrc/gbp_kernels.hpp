@@ -645,91 +645,89 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restr
 
 // ------------------------------------------------------------------ peer-store camera exchange --
 // Landmark-sharded sweep without a collective call: every rank owns a MAILBOX in its own
-// device memory -- two sweep-parity halves of [n_ranks][C*27] doubles and one arrival word per half and sender -- and the
-// kernel that produces a rank's camera partial sums stores them straight into the mailbox of EVERY rank (xGMI peer stores
-// on a multi-GPU node), then raises its arrival word there; the finish kernel of a rank waits for the n_ranks arrival words of
-// its own mailbox half and adds the parts in rank order.  Two halves are enough: a rank can write sweep k+2's sums only after
-// its own finish of sweep k+1, which needs every peer's sums of sweep k+1, which a peer produces after ITS finish of sweep k.
+// device memory -- two sweep-parity halves of [n_ranks][C] rows of 28 doubles: a camera's 27 partial sums and a tag -- and the
+// kernel that produces a rank's camera partial sums stores each row straight into the mailbox of EVERY rank (xGMI peer stores
+// on a multi-GPU node) and then raises the row's tag to the exchange number; whoever finishes camera c waits for the n_ranks tags
+// of row c in its own mailbox half and adds the parts in rank order.  Two halves are enough: a rank can write sweep k+2's sums only
+// after its own finish of sweep k+1, which needs every peer's sums of sweep k+1, which a peer produces after ITS finish of sweep k.
+//
+// No fences: a system-scope release / acquire fence on gfx950 writes back / invalidates a whole L2 (8000 waves doing that after the
+// sweep cost 120 us per reduce launch).  Every mailbox access is itself a system-scope relaxed atomic -- write-through stores, loads
+// that bypass the caches -- and "data before tag" is the s_waitcnt vmcnt(0) of the ONE wave that stores both: its data stores have
+// been acknowledged before it issues the tag store (/opt/skills/guides/MI355X_MICROARCH.md, hand-off with a separate flag).
 constexpr int MAX_PEERS = 16;
-constexpr int PEER_FLAG_STRIDE = 16;                  // arrival words are 128 bytes apart
+constexpr int PEER_ROW = 28;                          // doubles per mailbox row: 27 sums | tag (the exchange number, as 64 bits)
 struct PeerOut {
     int n;                                            // ranks (0: no peer stores)
-    double *dst[MAX_PEERS];                           // rank r's mailbox half of this sweep, the row of THIS rank: [C*27]
-    unsigned long long *flag[MAX_PEERS];              // this rank's arrival word in rank r's mailbox half
-    unsigned long long seq;                           // exchange number (1, 2, ...): the value the arrival words are raised to
-    int *arrived;                                     // workgroups of the producing launch that are done (zero between launches)
+    double *dst[MAX_PEERS];                           // rank r's mailbox half of this sweep, the block of THIS rank: [C][PEER_ROW]
+    unsigned long long seq;                           // exchange number (1, 2, ...): the value the tags are raised to
 };
 struct PeerWait {
-    const unsigned long long *flags;                  // [n_parts * PEER_FLAG_STRIDE] arrival words of this rank's mailbox half, or NULL
+    const double *src;                                // this rank's mailbox half: [n_parts][C][PEER_ROW], or NULL (parts are plain arrays)
     unsigned long long seq;
     long long timeout_ticks;                          // wall_clock64 ticks (100 MHz): a peer that never arrives must not hang the GPU
     int *err;                                         // set to 1 on time-out (reported by gbp_ba_sync)
     unsigned long long *clk;                          // instrumented runs: where workgroup 0 stores its start time, or NULL
 };
 
-// No fences: a system-scope release / acquire fence on gfx950 writes back / invalidates a whole L2 (8000 waves doing that after the
-// sweep cost 120 us per reduce launch).  Instead every mailbox access is itself a system-scope relaxed atomic -- write-through
-// stores, loads that bypass the caches -- and the order "data before flag" comes from s_waitcnt vmcnt(0) (the stores have been
-// acknowledged) before the workgroup barrier that precedes the arrival count.
 GBP_DEV void peer_store(double *dst, double v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 GBP_DEV double peer_load(const double *src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// the workgroup has stored its share of the partial sums into every mailbox: the last workgroup of the launch raises the flags
-GBP_DEV void peer_arrive(const PeerOut &peer)
+// ONE wave: lanes 0..26 hold camera c's partial sums; row c of this rank's block in every mailbox gets them, then the tag
+GBP_DEV void peer_push_row(const PeerOut &peer, int c, double v, int lane)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through peer stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(peer.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (int)gridDim.x - 1) {               // every workgroup's stores were acknowledged before it counted itself
-            __hip_atomic_store(peer.arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int r = 0; r < peer.n; ++r) __hip_atomic_store(peer.flag[r], peer.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    for (int r = 0; r < peer.n; ++r)
+        if (lane < 27) peer_store(peer.dst[r] + (size_t)c * PEER_ROW + lane, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through data stores have been acknowledged
+    if (lane == 0)
+        for (int r = 0; r < peer.n; ++r)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer.dst[r] + (size_t)c * PEER_ROW + 27), peer.seq, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// general path / update_all_beliefs: the partial sums already sit in `partial` (C*27): copy them into every mailbox
-__global__ __launch_bounds__(BLOCK) void k_peer_push(const double *__restrict__ partial, int n, PeerOut peer)
+// ONE wave: wait until all n_parts ranks have delivered row c of this exchange (one lane per rank polls); false on time-out
+GBP_DEV bool peer_wait_row(const PeerWait &wait, int n_parts, int C, int c, int lane)
 {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        const double v = partial[i];
-        for (int r = 0; r < peer.n; ++r) peer_store(peer.dst[r] + i, v);
+    bool ok = true;
+    if (lane < n_parts) {
+        const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(wait.src + ((size_t)lane * C + c) * PEER_ROW + 27);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != wait.seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > wait.timeout_ticks) { ok = false; break; }
+        }
     }
-    peer_arrive(peer);
+    ok = __all(ok);
+    if (!ok && lane == 0) atomicExch(wait.err, 1);
+    return ok;
+}
+
+// general path / update_all_beliefs: the partial sums already sit in `partial` (C*27): one wave per camera moves its row
+__global__ __launch_bounds__(BLOCK) void k_peer_push(const double *__restrict__ partial, int C, PeerOut peer)
+{
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;                                     // whole wave
+    peer_push_row(peer, c, lane < 27 ? partial[(size_t)c * 27 + lane] : 0.0, lane);
 }
 
 // belief_c = prior_c + sum over parts (fixed order) of part_r[c]; mu_c = Lambda^-1 eta.  One wavefront per camera: lane k < 27
 // adds entry k of the parts (coalesced 216-byte rows) in rank order, lane 0 collects the 27 sums and solves the 6x6.
-// With wait.flags the parts are a mailbox half: the first wave of the workgroup polls the arrival words (one lane per rank) first.
-constexpr int FINISH_BLOCK = 256;
-__global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const double *gathered, int n_parts, size_t part_stride, PeerWait wait)
+// With wait.src the parts are rows of a mailbox half: the camera's wave polls the n_parts tags of its row first (one lane per rank).
+// one WAVE finishes camera c (shared by k_cam_finish and the merged reduce-exchange-finish kernel of gbp_fused.hpp)
+GBP_DEV void cam_finish_wave(const Params &p, const double *gathered, int n_parts, size_t part_stride, const PeerWait &wait, int c, int lane)
 {
-    if (wait.clk && blockIdx.x == 0 && threadIdx.x == 0) *wait.clk = (unsigned long long)wall_clock64();
-    if (wait.flags) {
-        if (threadIdx.x < 64) {
-            bool ok = true;
-            if ((int)threadIdx.x < n_parts) {
-                const unsigned long long *f = wait.flags + (size_t)threadIdx.x * PEER_FLAG_STRIDE;
-                const long long t0 = wall_clock64();
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < wait.seq) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > wait.timeout_ticks) { ok = false; break; }
-                }
-            }
-            if (!__all(ok) && threadIdx.x == 0) atomicExch(wait.err, 1);
-        }
-        __syncthreads();                              // (the parts are read with cache-bypassing loads below: no acquire fence needed)
-    }
-    const int lane = threadIdx.x & 63, c = blockIdx.x * (FINISH_BLOCK / 64) + (threadIdx.x >> 6);
-    if (c >= p.C) return;                                   // whole wave
     double acc = 0.0;
-    if (lane < 27) {
+    if (wait.src) {                                         // the parts are rows of this rank's mailbox half
+        peer_wait_row(wait, n_parts, p.C, c, lane);
+        if (lane < 27) {
+            acc = p.cprior[(size_t)c * 27 + lane];
+            for (int r = 0; r < n_parts; ++r) acc += peer_load(wait.src + ((size_t)r * p.C + c) * PEER_ROW + lane);
+        }
+    } else if (lane < 27) {
         acc = p.cprior[(size_t)c * 27 + lane];
-        if (wait.flags) for (int r = 0; r < n_parts; ++r) acc += peer_load(gathered + (size_t)r * part_stride + (size_t)c * 27 + lane);
-        else for (int r = 0; r < n_parts; ++r) acc += gathered[(size_t)r * part_stride + (size_t)c * 27 + lane];
-        p.cbel[(size_t)c * CAMREC + CAM_ETA + lane] = acc;
+        for (int r = 0; r < n_parts; ++r) acc += gathered[(size_t)r * part_stride + (size_t)c * 27 + lane];
     }
+    if (lane < 27) p.cbel[(size_t)c * CAMREC + CAM_ETA + lane] = acc;
     double v[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) v[k] = __shfl(acc, k, 64);
@@ -745,6 +743,15 @@ __global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const dou
         for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
         rec[33] = 0.0;
     }
+}
+
+constexpr int FINISH_BLOCK = 256;
+__global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const double *gathered, int n_parts, size_t part_stride, PeerWait wait)
+{
+    if (wait.clk && blockIdx.x == 0 && threadIdx.x == 0) *wait.clk = (unsigned long long)wall_clock64();
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (FINISH_BLOCK / 64) + (threadIdx.x >> 6);
+    if (c >= p.C) return;                                   // whole wave
+    cam_finish_wave(p, gathered, n_parts, part_stride, wait, c, lane);
 }
 
 // instrumented runs: the stamp ring starts empty

@@ -57,6 +57,7 @@ class _HipShard:
         self.engine = BAEngine.from_problem(problem, device=device, fused=fused, **cfg)
         self.partial_doubles = CAM_PARTIAL_DOUBLES
         self.device = torch.device('cuda', device)
+        self.side_device = self.device                       # where the side channel's small tensors live (CPU under a gloo group)
         # kernels and the collective are ordered on ONE side stream of torch's (a real handle: the legacy default
         # stream is the null pointer, which gbp_ba_set_stream reads as "the engine's own stream")
         self.stream = torch.cuda.Stream(self.device)
@@ -73,6 +74,8 @@ class _HipShard:
         'auto' = 'callback' when the dist object has one, else 'rccl'."""
         rank, world = dist.get_rank(), dist.get_world_size()
         threads = hasattr(dist, 'device_exchange')           # ranks are threads of ONE process on one device
+        if not threads and hasattr(dist, 'get_backend') and dist.get_backend() == 'gloo':
+            self.side_device = self.torch.device('cpu')      # a CPU side channel (ranks that share one GPU cannot form an RCCL group)
         if exchange == 'auto':
             exchange = 'callback' if threads else 'rccl'
         if exchange == 'callback':
@@ -128,10 +131,10 @@ class _HipShard:
         self.engine.shard_end(gathered.data_ptr(), world)
 
     def to_tensor(self, a):
-        return self.torch.as_tensor(np.ascontiguousarray(a), device=self.device)
+        return self.torch.as_tensor(np.ascontiguousarray(a), device=self.side_device)
 
     def sync(self):
-        self.stream.synchronize()
+        self.engine.sync()                                   # the engine runs on self.stream; its sync also reports a peer exchange that timed out
 
 
 class ShardedBA:

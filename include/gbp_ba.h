@@ -163,16 +163,17 @@ int gbp_ba_comm_unique_id(void *id128, const char *rccl_path);
 int gbp_ba_comm_init_rccl(gbp_ba_t *h, const void *id128, int32_t rank, int32_t n_ranks, int32_t flags, const char *rccl_path);
 int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank, int32_t n_ranks, int32_t flags);
 int gbp_ba_comm_destroy(gbp_ba_t *h);
-/*   - gbp_ba_peer_export / gbp_ba_peer_connect: NO collective call.  Every rank owns a mailbox in its own device memory; the
- *     kernel that finishes a rank's partial sums stores them straight into the mailbox of every rank (peer stores over xGMI
- *     on a multi-GPU node) and raises an arrival word, the finish kernel of a rank polls the arrival words of its own
- *     mailbox.  export allocates the mailbox for n_ranks and writes a 64-byte handle (a hipIpcMemHandle_t for other
- *     PROCESSES; with GBP_PEER_SAME_PROCESS the raw device address, for ranks that are threads of one process); carry the
- *     handles of all ranks, in rank order, to every rank over any side channel and pass them to connect.  All ranks must
- *     have connected before the first sharded call (barrier on the side channel).  GBP_PEER_RENDEZVOUS keeps the function
- *     set with gbp_ba_set_exchange as a hook called with (NULL, NULL, 0, stream) between the stores and the finish (logical
- *     ranks on ONE device must not spin on each other).  A finish kernel gives up after GBP_PEER_TIMEOUT_MS (default
- *     20000) and gbp_ba_sync then returns GBP_ESTATE. */
+/*   - gbp_ba_peer_export / gbp_ba_peer_connect: NO collective call.  Every rank owns a mailbox in its own device memory (two
+ *     sweep-parity halves of n_ranks x C rows: a camera's 27 partial sums + a tag); the kernel that finishes a rank's partial sums
+ *     stores each row straight into the mailbox of every rank (peer stores over xGMI on a multi-GPU node) and then raises the
+ *     row's tag; whoever finishes camera c polls the n_ranks tags of row c in its own mailbox.  After the fused sweep all of that
+ *     is ONE launch (reduce -> push -> wait -> rank-ordered sum + prior + 6x6 solve).  export allocates the mailbox for n_ranks and
+ *     writes a 64-byte handle (a hipIpcMemHandle_t for other PROCESSES; with GBP_PEER_SAME_PROCESS the raw device address, for
+ *     ranks that are threads of one process); carry the handles of all ranks, in rank order, to every rank over any side channel
+ *     and pass them to connect.  All ranks must have connected before the first sharded call (barrier on the side channel).
+ *     GBP_PEER_RENDEZVOUS keeps the function set with gbp_ba_set_exchange as a hook called with (NULL, NULL, 0, stream) between
+ *     the stores and the finish, which then stay two launches (logical ranks on ONE device must not spin on each other).  A
+ *     finish wave gives up after GBP_PEER_TIMEOUT_MS (default 20000) and gbp_ba_sync then returns GBP_ESTATE. */
 #define GBP_PEER_HANDLE_BYTES 64
 #define GBP_PEER_SAME_PROCESS 1
 #define GBP_PEER_RENDEZVOUS 2

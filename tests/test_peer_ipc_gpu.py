@@ -1,0 +1,82 @@
+"""The peer-store camera exchange between real PROCESSES (gbp_ba_peer_export / gbp_ba_peer_connect with hipIpc handles): two
+and three ranks, each its own process, all on the one GPU this box has.  What the thread-rank tests cannot show: mailboxes mapped
+across address spaces, kernels of different processes that genuinely wait for each other's stores (no rendezvous on the host:
+the merged reduce-exchange-finish launch polls the row tags), the time-out instead of a hang when a rank never arrives."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, rel_err_rows
+from gbp_amd.synthetic import make_synthetic
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(REPO, 'tests', 'peer_ipc_worker.py')
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks, extra_env=None):
+    port = free_port()
+    # The ranks SHARE one GPU here: a rank that waits inside its exchange launch holds LDS on the CUs it sits on, and another rank's
+    # fused sweep needs a whole CU's LDS per workgroup -- with the production grid (128 workgroups) two waiting ranks can leave the
+    # third no CU at all until the driver time-slices the processes.  16 waiting workgroups per rank leave room.  (One rank per GPU,
+    # the real deployment, has no such coupling.)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_XCHG_BLOCKS='16', **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(tmp_path), str(n_sweeps), str(n_cams), str(n_lmks)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors='replace'))
+    for pr, out in zip(procs, outs):
+        assert pr.returncode == 0, out[-3000:]
+    return [np.load(os.path.join(tmp_path, f'rank{r}.npz')) for r in range(world)]
+
+
+@pytest.mark.parametrize('world,n_cams,n_lmks', [(2, 60, 4000), (3, 500, 20000)])
+def test_peer_exchange_between_processes(tmp_path, world, n_cams, n_lmks):
+    from gbp_amd.engine import BAEngine
+    n_sweeps = 12
+    p = make_synthetic(n_cams=n_cams, n_lmks=n_lmks, obs_per_lmk=10, seed=2)
+    ref = BAEngine.from_problem(p)
+    ref.generate_priors_var(50.0)
+    ref.update_all_beliefs()
+    ref.iterate(n_sweeps)
+    rce, rcl, rle, rll = ref.beliefs()
+    are = ref.are()
+    ref.close()
+    ranks = run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks)
+    assert sum(int(r['F']) for r in ranks) == p.n_factors
+    lo = 0
+    for r in ranks:
+        assert str(r['kind']) == 'peer' and int(r['n_ranks']) == world
+        assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])   # identical on every rank
+        assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
+        a, b = int(r['lo']), int(r['hi'])
+        assert a == lo
+        lo = b
+        assert rel_err_rows(r['le'], rle[a:b]) < 1e-6 and rel_err_rows(r['ll'], rll[a:b]) < 1e-6
+        assert float(r['are']) == pytest.approx(are, rel=1e-8)
+    assert lo == p.n_lmks
+
+
+def test_peer_exchange_split_launches_between_processes(tmp_path):
+    """GBP_PEER_SPLIT=1: reduce / push and the waiting finish as two launches (what the general sweep and update_all_beliefs always
+    use), also across processes."""
+    ranks = run_ranks(tmp_path, 2, 6, 40, 2000, extra_env={'GBP_PEER_SPLIT': '1'})
+    assert np.array_equal(ranks[0]['ce'], ranks[1]['ce'])

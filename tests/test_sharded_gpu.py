@@ -297,3 +297,23 @@ def test_full_size_sharded_config5(full_size_single, world, exchange):
             assert rel_err_rows(r['ll'][s[mine] - a], g9b[tag + '_lmk_lam'][mine]) < 1e-6
     assert lo == p.n_lmks
     assert ref['relin'][7] > p.n_factors // 2 and not ref['relin'][:7].any()
+
+
+def test_peer_exchange_times_out_instead_of_hanging(monkeypatch):
+    """A rank whose peer never delivers: the finish waves give up after GBP_PEER_TIMEOUT_MS and gbp_ba_sync reports it -- the GPU is
+    never left spinning."""
+    from gbp_amd.engine import BAEngine
+    from gbp_amd._capi import GbpError
+    monkeypatch.setenv('GBP_PEER_TIMEOUT_MS', '150')
+    p = make_synthetic(n_cams=20, n_lmks=400, obs_per_lmk=6, seed=1)
+    a, b = BAEngine.from_problem(p), BAEngine.from_problem(p)
+    handles = [a.peer_export(2, same_process=True), b.peer_export(2, same_process=True)]
+    a.peer_connect(0, handles, same_process=True)
+    b.peer_connect(1, handles, same_process=True)
+    a.generate_priors_var(50.0)
+    a.update_beliefs_sharded()                                # rank 1 never runs: its rows never arrive
+    with pytest.raises(GbpError) as ei:
+        a.sync()
+    assert ei.value.code == -5 and 'timed out' in str(ei.value)
+    a.sync()                                                  # the error is reported once
+    a.close(); b.close()
