@@ -107,6 +107,18 @@ constexpr int NPHASE = 12;
 #endif
 
 
+// A/B switches for the factor streams of the fused sweep (tools/ab_nt.sh builds the variants): nontemporal loads / stores
+#ifdef GBP_NT_LOADS
+#define GBP_LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define GBP_LD(ptr) (*(ptr))
+#endif
+#ifdef GBP_NT_STORES
+#define GBP_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define GBP_ST(ptr, v) (*(ptr) = (v))
+#endif
+
 template <int LOSS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles,
                                                                           const int *__restrict__ blk_begin)
@@ -166,15 +178,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         const unsigned meta = p.meta[slot];
         int st = p.state[slot];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-        z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
-        if (LOSS != 0) avar = p.lin[lin_at(slot, ROW_AVAR)];
+        for (int k = 0; k < 9; ++k) x0[k] = GBP_LD(&p.lin[lin_at(slot, ROW_X0 + k)]);
+        z[0] = GBP_LD(&p.lin[lin_at(slot, ROW_Z)]); z[1] = GBP_LD(&p.lin[lin_at(slot, ROW_Z + 1)]);
+        if (LOSS != 0) avar = GBP_LD(&p.lin[lin_at(slot, ROW_AVAR)]);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { qC[k] = p.msg[msg_at(slot, ROW_QC + k)]; qL[k] = p.msg[msg_at(slot, ROW_QL + k)]; }
+        for (int k = 0; k < 2; ++k) { qC[k] = GBP_LD(&p.msg[msg_at(slot, ROW_QC + k)]); qL[k] = GBP_LD(&p.msg[msg_at(slot, ROW_QL + k)]); }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
+        for (int k = 0; k < 3; ++k) WC[k] = GBP_LD(&p.msg[msg_at(slot, ROW_WC + k)]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+        for (int k = 0; k < 3; ++k) VL[k] = GBP_LD(&p.msg[msg_at(slot, ROW_VL + k)]);
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
@@ -232,13 +244,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
                 for (int k = 0; k < 9; ++k) p.lin[lin_at(sslot, ROW_X0 + k)] = x0[k];
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { p.msg[msg_at(sslot, ROW_QC + k)] = qC[k]; p.msg[msg_at(sslot, ROW_QL + k)] = qL[k]; }
+            for (int k = 0; k < 2; ++k) { GBP_ST(&p.msg[msg_at(sslot, ROW_QC + k)], qC[k]); GBP_ST(&p.msg[msg_at(sslot, ROW_QL + k)], qL[k]); }
 #pragma unroll
             for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) p.msg[msg_at(sslot, ROW_WC + k)] = WC[k];
+            for (int k = 0; k < 3; ++k) GBP_ST(&p.msg[msg_at(sslot, ROW_WC + k)], WC[k]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) p.msg[msg_at(sslot, ROW_VL + k)] = VL[k];
+            for (int k = 0; k < 3; ++k) GBP_ST(&p.msg[msg_at(sslot, ROW_VL + k)], VL[k]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
             p.state[sslot] = st;
