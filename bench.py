@@ -148,7 +148,7 @@ def measured_traffic():
         return None, None
 
 
-def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_graph):
+def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_graph, side_dev='cuda'):
     """N > 1: the same job once more with the peer-store exchange (gbp_ba_peer_connect: the reduce kernels store the camera partial
     sums straight into every rank's mailbox over xGMI, the finish kernels poll arrival words; no collective call).  Every step
     is agreed on by all ranks; any failure (IPC handles, a time-out in the two-sweep probe) just returns None.  Returns the
@@ -157,7 +157,7 @@ def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_grap
     os.environ.setdefault('GBP_PEER_TIMEOUT_MS', '3000')
 
     def agreed(ok):
-        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device='cuda')
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=side_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
 
@@ -259,6 +259,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dry = args.engine_factory is not None
+    side_dev = 'cpu' if (dry or args.backend == 'gloo') else 'cuda'      # where the side channel's few scalars live
+    if os.environ.get('GBP_BENCH_SHARE_GPU'):                             # tests on a one-GPU box: every rank on device 0 (gloo + peer exchange)
+        local_rank = 0
     if not dry:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a MI355X: the HIP engine has no CPU fallback")
@@ -288,7 +291,7 @@ def main():
         else:
             if 'MASTER_ADDR' not in os.environ:                     # --sharded without torchrun: a one-rank group of our own
                 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
-            dist.init_process_group(args.backend, device_id=torch.device('cuda', local_rank))
+            dist.init_process_group(args.backend, **({} if args.backend == 'gloo' else {'device_id': torch.device('cuda', local_rank)}))
             graph = ShardedBA(problem, device=local_rank, fused=not args.no_fused, library_loop=not args.python_loop,
                               always_exchange=args.sharded, exchange='peer' if args.exchange == 'peer' else 'rccl')
     else:
@@ -324,7 +327,7 @@ def main():
             fence()
             dt = time.perf_counter() - t0
             if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else 'cuda')
+                t = torch.tensor([dt], dtype=torch.float64, device=side_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             return dt
@@ -390,7 +393,7 @@ def main():
     alt = None
     if world > 1 and not dry and args.exchange == 'auto' and exchange_used == 'rccl':
         # the same job with the peer-store exchange (no collective call: reduce kernels store into the ranks' mailboxes over xGMI)
-        alt = try_peer_exchange(args, problem, local_rank, dist, torch, measure, graph)
+        alt = try_peer_exchange(args, problem, local_rank, dist, torch, measure, graph, side_dev)
         if alt is not None and float(np.median(alt['times'])) < dt_med and alt.get('matches_rccl'):
             m, alt = alt, dict(m, exchange='rccl')
             times = m['times']
@@ -407,7 +410,7 @@ def main():
     if dist is not None and not dry and pic['n']:
         mine = [mean_ms(pic[k], pic['ok']) or 0.0 for k in ('sweep', 'reduce', 'finish')] + [mean_ms(pic['step'], pic['ok'][:-1]) or 0.0,
                 float(graph.F), float(graph.comm_info()['n_ranks'])]
-        t = torch.tensor(mine, dtype=torch.float64, device='cuda')
+        t = torch.tensor(mine, dtype=torch.float64, device=side_dev)
         allr = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allr, t)
         per_rank = [dict(rank=r, sweep_ms=v[0], reduce_and_exchange_ms=v[1], finish_ms=v[2], step_ms_device=v[3], n_factors=int(v[4]),

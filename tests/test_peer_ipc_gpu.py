@@ -80,3 +80,24 @@ def test_peer_exchange_split_launches_between_processes(tmp_path):
     use), also across processes."""
     ranks = run_ranks(tmp_path, 2, 6, 40, 2000, extra_env={'GBP_PEER_SPLIT': '1'})
     assert np.array_equal(ranks[0]['ce'], ranks[1]['ce'])
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path on hardware, as far as a one-GPU box allows: `--gpus 2` spawns its two ranks (torchrun on 127.0.0.1), both
+    on device 0 (GBP_BENCH_SHARE_GPU), side channel gloo, camera exchange = peer stores between the two processes.  The line must
+    carry both ranks' device times and the rank count the exchange reports.  (Its `value` is two ranks time-slicing one GPU: not a
+    measurement of anything.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(GBP_BENCH_SHARE_GPU='1', GBP_XCHG_BLOCKS='16', HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_PEER_TIMEOUT_MS='8000')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--lmks', '20000',
+           '--backend', 'gloo', '--exchange', 'peer', '--single-batch']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['exchange'] == 'peer' and out['config']['loop'] == 'in-library'
+    assert len(out['per_rank']) == 2 and all(pr['ranks_reported_by_exchange'] == 2 for pr in out['per_rank'])
+    assert sum(pr['n_factors'] for pr in out['per_rank']) == 200_000
+    assert all(pr['sweep_ms'] > 0 and pr['reduce_and_exchange_ms'] > 0 for pr in out['per_rank'])
