@@ -1,6 +1,6 @@
 """Randomised shapes through the landmark-sharded driver at world sizes 2-4 (thread ranks on one GPU, tests/test_sharded_gpu.py)
 against ONE engine on the same graph: ragged partitions, ranks that own a single landmark or none, cameras a rank never sees,
-over-sized landmarks, every loss, random sweep flags, both sweeps, both loops.  The graphs are those of test_fuzz_gpu.py."""
+over-sized landmarks, every loss, random sweep flags, both sweeps, both loops, both in-library exchanges (callback / peer stores).  The graphs are those of test_fuzz_gpu.py."""
 import os
 import threading
 
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 N_SEEDS = int(os.environ.get('GBP_FUZZ_SEEDS', 18))
 
 
-def sharded_run(p, world, fused, library_loop, cfg, flags):
+def sharded_run(p, world, fused, library_loop, cfg, flags, exchange='auto'):
     from gbp_amd.sharded import ShardedBA
     shared = LockstepWorld(world)
     out, errors = [None] * world, []
@@ -24,7 +24,8 @@ def sharded_run(p, world, fused, library_loop, cfg, flags):
         try:
             import torch
             torch.cuda.set_device(0)
-            g = ShardedBA(p, device=0, fused=fused, dist=LockstepDist(shared, r), library_loop=library_loop, **cfg)
+            g = ShardedBA(p, device=0, fused=fused, dist=LockstepDist(shared, r), library_loop=library_loop, exchange=exchange, **cfg)
+            assert not library_loop or g.exchange == ('callback' if exchange == 'auto' else exchange)
             g.generate_priors_var(30.0)
             g.update_all_beliefs()
             for rob, rel in flags:
@@ -71,7 +72,9 @@ def test_sharded_random_shapes(oracle_mod, seed):
     if not np.isfinite(spread) or spread > 1e-4 or not all(np.isfinite(x).all() for x in rb):
         pytest.skip('the run blew up on one engine as well (about 7 % of the seeds: aggressive settings on tiny graphs)')
     tol = max(1e-7, 4.0 * spread)
-    ranks = sharded_run(p, world, fused, library_loop, cfg, flags)
+    # odd seeds: the peer-store exchange (mailboxes + tags; fused and general sweeps, camera groups, every loss), even seeds: the
+    # plugged-in all-gather
+    ranks = sharded_run(p, world, fused, library_loop, cfg, flags, exchange='peer' if (seed % 2 and library_loop) else 'auto')
     rce, rcl, rle, rll = rb
     lo = 0
     for r in ranks:
