@@ -9,11 +9,13 @@
 //   3. sort_pairs             stable by landmark    -> landmark-major list lm2ref (adj_factors order), offsets lptr
 //   4. tile packing           next-fit over the landmark degrees (64 slots / 24 landmarks per tile, landmarks above 64 factors
 //                             cut into chunk tiles).  Next-fit is a chain -- where a tile starts depends on where the previous one
-//                             ended -- so it is done as LIST RANKING: k_pack_next gives every landmark the landmark the next
-//                             tile would start at IF a tile started here, pointer doubling (k_pack_double) builds 2^k-hop jump
-//                             tables with the number of tiles they cross, and k_pack_mark walks them from the top level down,
-//                             handing every landmark that really starts a tile its tile index; k_pack_emit writes the tile
-//                             table and the slot ranges.  Two ints (tile count, over-sized landmarks) come back to the host
+//                             ended -- so it is done as LIST RANKING, in two levels: k_pack_next gives every landmark the
+//                             landmark the next tile would start at IF a tile started here; k_pack_block_walk condenses that
+//                             into a list over (block of 128 landmarks, entry offset) nodes; pointer doubling (k_pack_double)
+//                             builds 2^k-hop jump tables over THAT list with the number of tiles they cross, k_pack_mark walks
+//                             them from the top level down, k_pack_block_fill hands every landmark that really starts a tile
+//                             its tile index; k_pack_emit writes the tile table and the slot ranges.  Two ints (tile count,
+//                             over-sized landmarks) come back to the host
 //   5. k_build_tiles          one wave per tile: every slot finds its factor, writes x0 | z | variance, meta, state (with the
 //                             factor's rank among the same-camera factors of its tile) and both directions of the
 //                             reference-id <-> slot map
@@ -83,6 +85,48 @@ __global__ __launch_bounds__(BLOCK) void k_pack_next(const int *__restrict__ lpt
         nf += d; ++nl; ++e;
     }
     nxt[l] = e; w[l] = 1;
+}
+
+// The chain is ranked in two levels so that the scratch stays O(L) (log L jump tables over all landmarks were 1.9 GB of transient
+// memory at 10M landmarks).  Landmarks are cut into blocks of PACK_BLOCK; a tile spans at most TILE_LMKS landmarks, so the chain can
+// enter a block only at one of its first TILE_LMKS landmarks.  k_pack_block_walk follows the chain through ONE block from each of
+// those possible entries (a short sequential walk) and records where it enters the next block and how many tiles start on the way:
+// a list over (block, entry) nodes, ~L/5 of them, which pointer doubling (k_pack_double / k_pack_mark, as before) ranks from node
+// (0, 0); k_pack_block_fill then walks every block once more from the entry the chain really takes and hands the landmarks that
+// start a tile their tile index.
+constexpr int PACK_BLOCK = 128;
+
+// node = b * TILE_LMKS + e; the last node (n_nodes - 1) is the end of the chain
+__global__ __launch_bounds__(BLOCK) void k_pack_block_walk(const int *__restrict__ nxt, const int *__restrict__ w, int L, int n_blocks,
+                                                           int *__restrict__ bnext, int *__restrict__ bw)
+{
+    const int node = blockIdx.x * BLOCK + threadIdx.x, end_node = n_blocks * TILE_LMKS;
+    if (node > end_node) return;
+    if (node == end_node) { bnext[node] = node; bw[node] = 0; return; }
+    const int b = node / TILE_LMKS, e = node - b * TILE_LMKS, stop = min((b + 1) * PACK_BLOCK, L);
+    int l = b * PACK_BLOCK + e, count = 0;
+    if (l >= stop && l < L) { bnext[node] = node; bw[node] = 0; return; }      // (an entry offset beyond a short last block: never reached)
+    while (l < stop) { count += w[l]; l = nxt[l]; }
+    bnext[node] = l >= L ? end_node : (b + 1) * TILE_LMKS + (l - (b + 1) * PACK_BLOCK);
+    bw[node] = count;
+}
+
+// one thread per block: the entry the chain takes (the only marked node of the block) and the tile index it arrives with
+__global__ __launch_bounds__(BLOCK) void k_pack_block_fill(const int *__restrict__ nxt, const int *__restrict__ w, int L, int n_blocks,
+                                                           const int *__restrict__ bpos, int *__restrict__ pos)
+{
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= n_blocks) return;
+    int e = -1, t = 0;
+    for (int k = 0; k < TILE_LMKS; ++k) {
+        const int q = bpos[b * TILE_LMKS + k];
+        if (q >= 0) { e = k; t = q; break; }
+    }
+    if (e < 0) return;                                   // (cannot happen for b * PACK_BLOCK < L: every block is crossed)
+    const int stop = min((b + 1) * PACK_BLOCK, L);
+    int l = b * PACK_BLOCK + e;
+    while (l < stop) { pos[l] = t; t += w[l]; l = nxt[l]; }
+    if (l >= L) pos[L] = t;                              // the chain ends in this block: the total number of tiles
 }
 
 // one doubling step: 2^(k+1) hops = 2^k hops twice

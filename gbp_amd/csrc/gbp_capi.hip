@@ -587,22 +587,29 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     //    Next-fit packing as list ranking on the device (gbp_build.hpp); only the tile count and the (few) over-sized landmarks
     //    come back.
     const int LP = L + 1;
+    const int n_pblocks = std::max(1, (L + PACK_BLOCK - 1) / PACK_BLOCK), n_nodes = n_pblocks * TILE_LMKS + 1;   // (block, entry) nodes + the end
     int levels = 1;
-    while ((1 << levels) < LP) ++levels;
-    int *jump = nullptr, *wsum = nullptr, *pos = nullptr, *d_lrow0 = nullptr, *d_lrow1 = nullptr, *d_big_list = nullptr, *d_cnt = nullptr;
-    CHK(scratch_alloc(h, scratch, &jump, (size_t)levels * LP)); CHK(scratch_alloc(h, scratch, &wsum, (size_t)levels * LP));
-    CHK(scratch_alloc(h, scratch, &pos, (size_t)LP));
+    while ((1 << levels) < n_pblocks + 1) ++levels;
+    int *nxt = nullptr, *w0 = nullptr, *jump = nullptr, *wsum = nullptr, *bpos = nullptr, *pos = nullptr, *d_lrow0 = nullptr, *d_lrow1 = nullptr,
+        *d_big_list = nullptr, *d_cnt = nullptr;
+    CHK(scratch_alloc(h, scratch, &nxt, (size_t)LP)); CHK(scratch_alloc(h, scratch, &w0, (size_t)LP));
+    CHK(scratch_alloc(h, scratch, &jump, (size_t)levels * n_nodes)); CHK(scratch_alloc(h, scratch, &wsum, (size_t)levels * n_nodes));
+    CHK(scratch_alloc(h, scratch, &bpos, (size_t)n_nodes)); CHK(scratch_alloc(h, scratch, &pos, (size_t)LP));
     CHK(scratch_alloc(h, scratch, &d_lrow0, (size_t)L)); CHK(scratch_alloc(h, scratch, &d_lrow1, (size_t)L));
     CHK(scratch_alloc(h, scratch, &d_big_list, (size_t)L)); CHK(scratch_alloc(h, scratch, &d_cnt, 1));
     HIPCHK(hipMemsetAsync(pos, 0xff, sizeof(int) * (size_t)LP, h->stream));
-    HIPCHK(hipMemsetAsync(pos, 0, sizeof(int), h->stream));                       // the first tile starts at landmark 0
+    HIPCHK(hipMemsetAsync(bpos, 0xff, sizeof(int) * (size_t)n_nodes, h->stream));
+    HIPCHK(hipMemsetAsync(bpos, 0, sizeof(int), h->stream));                      // the chain enters block 0 at landmark 0 with tile 0
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_pack_next, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, lptr, L, jump, wsum);
+    hipLaunchKernelGGL(k_pack_next, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, lptr, L, nxt, w0);
+    hipLaunchKernelGGL(k_pack_block_walk, dim3(grid_for((size_t)n_nodes)), dim3(BLOCK), 0, h->stream, nxt, w0, L, n_pblocks, jump, wsum);
     for (int k = 0; k + 1 < levels; ++k)
-        hipLaunchKernelGGL(k_pack_double, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, jump + (size_t)k * LP, wsum + (size_t)k * LP,
-                           jump + (size_t)(k + 1) * LP, wsum + (size_t)(k + 1) * LP, LP);
+        hipLaunchKernelGGL(k_pack_double, dim3(grid_for((size_t)n_nodes)), dim3(BLOCK), 0, h->stream, jump + (size_t)k * n_nodes, wsum + (size_t)k * n_nodes,
+                           jump + (size_t)(k + 1) * n_nodes, wsum + (size_t)(k + 1) * n_nodes, n_nodes);
     for (int k = levels - 1; k >= 0; --k)
-        hipLaunchKernelGGL(k_pack_mark, dim3(grid_for((size_t)LP)), dim3(BLOCK), 0, h->stream, jump + (size_t)k * LP, wsum + (size_t)k * LP, pos, LP);
+        hipLaunchKernelGGL(k_pack_mark, dim3(grid_for((size_t)n_nodes)), dim3(BLOCK), 0, h->stream, jump + (size_t)k * n_nodes, wsum + (size_t)k * n_nodes, bpos,
+                           n_nodes);
+    hipLaunchKernelGGL(k_pack_block_fill, dim3(grid_for((size_t)n_pblocks)), dim3(BLOCK), 0, h->stream, nxt, w0, L, n_pblocks, bpos, pos);
     HIPCHK(hipGetLastError());
     int T = 0;
     HIPCHK(hipMemcpyAsync(&T, pos + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -613,7 +620,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     p.T = T;
     int4 *d_tiles = nullptr;
     CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1)));
-    if (L) hipLaunchKernelGGL(k_pack_emit, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, jump, pos, d_tiles, d_lrow0, d_lrow1,
+    if (L) hipLaunchKernelGGL(k_pack_emit, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, nxt, pos, d_tiles, d_lrow0, d_lrow1,
                               d_big_list, d_cnt);
     HIPCHK(hipGetLastError());
     int n_big = 0;
