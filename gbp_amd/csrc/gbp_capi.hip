@@ -1669,6 +1669,7 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h)
     for (size_t i = 0; i < parts.size(); ++i)
         if (parts[i].bytes) HIPCHK(hipMemcpyAsync(parts[i].dev, h->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
     h->has_beliefs = h->snap_has_beliefs;
+    h->pending_possible = true;                              // (the restored state words may carry pending relinearisations)
     h->walk_parity = h->snap_parity;
     return GBP_OK;
 }
@@ -1697,6 +1698,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->has_beliefs = hd.has_beliefs != 0;
+    h->pending_possible = true;                              // (the loaded state words may carry pending relinearisations)
     h->walk_parity = hd.walk_parity & 1u;
     return GBP_OK;
 }
