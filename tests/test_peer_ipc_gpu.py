@@ -48,8 +48,10 @@ def run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks, extra_env=None):
     return [np.load(os.path.join(tmp_path, f'rank{r}.npz')) for r in range(world)]
 
 
-@pytest.mark.parametrize('world,n_cams,n_lmks', [(2, 60, 4000), (3, 500, 20000)])
+@pytest.mark.parametrize('world,n_cams,n_lmks', [(2, 60, 4000), (3, 500, 20000), (4, 500, 100000)])
 def test_peer_exchange_between_processes(tmp_path, world, n_cams, n_lmks):
+    """(4, 500, 100000) is BASELINE configs[4] at full size -- the 1M-factor graph over four ranks -- between real processes: 12 sweeps
+    through the one that relinearises every factor."""
     from gbp_amd.engine import BAEngine
     n_sweeps = 12
     p = make_synthetic(n_cams=n_cams, n_lmks=n_lmks, obs_per_lmk=10, seed=2)
