@@ -1124,8 +1124,8 @@ int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *
 // one sharded sweep (or belief update) on the handle's stream: local kernels -> camera partial sums -> exchange -> rank-ordered
 // sum + prior + 6x6 solve.  With one rank and no GBP_XCH_ALWAYS nothing is exchanged and the camera beliefs are finished by
 // the reduce launch itself, exactly like gbp_ba_iterate.
-// one sharded sweep under the peer-store exchange: no collective, no host synchronisation -- the reduce kernel stores this rank's
-// partial sums into every rank's mailbox and raises the arrival words, the finish kernel waits for all of them
+// one sharded sweep under the peer-store exchange: no collective, no host synchronisation -- the wave that finishes a camera's partial
+// sums stores the row into every rank's mailbox and raises its tag; whoever finishes the camera waits for the n_ranks tags of its row
 static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int local_relin)
 {
     gbp_ba::Peer &pe = h->peer;

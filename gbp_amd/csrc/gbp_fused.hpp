@@ -431,10 +431,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
 // then finishes them, one wave per camera: wait for the n_ranks tags of row c, add the parts in rank order, prior, 6x6 solve.
 // Every workgroup of every rank pushes before it waits, and the grid is never larger than what is resident at once (XCHG_BLOCKS = two
 // 1024-thread workgroups per CU of an MI355X; one camera per workgroup up to 512 cameras, several beyond), so ranks cannot wait for
-// each other in a cycle.  Against reduce -> finish as two launches
+// each other in a cycle (__launch_bounds__(1024, 8): 64 VGPRs, the 6x6 solve of the finish spills ~40 of them -- one lane, once per
+// camera -- so that TWO workgroups fit a CU; fused_launch caps the grid at what the occupancy query admits).  Against reduce -> finish as two launches
 // this saves a kernel boundary and the global "all rows are out" hand-off; against RCCL also the collective's launch and sync.
 constexpr int XCHG_BLOCKS = 512;
-__global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
+__global__ __launch_bounds__(RED_THREADS, 8) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
                                                                  double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][28] | red[RED_PARTS][27]
@@ -485,6 +486,7 @@ struct FusedPlan {
     int n_groups = 0, group_cams = 0, pass_cams = 0; // the sweep adds up the first group_cams cameras, every k_cam_pass launch pass_cams more
     size_t pass_shmem = 0;
     int n_blocks = 0, n_big = 0;
+    int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     size_t shmem = 0;
     FusedArgs args{};
     const int *d_blk = nullptr;
@@ -608,7 +610,18 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     PeerOut po{};
     if (peer) po = *peer;
     if (merged && peer) {                                   // reduce -> push -> wait -> finish in one launch (peer-store exchange)
-        static const int xb = getenv("GBP_XCHG_BLOCKS") ? std::max(1, atoi(getenv("GBP_XCHG_BLOCKS"))) : XCHG_BLOCKS;
+        // The grid must be resident at once (its workgroups wait for other ranks' workgroups of the same index, and the dispatch order
+        // is nobody's contract): never more workgroups than the occupancy query admits on this device.
+        int xb = pl.xchg_blocks;
+        if (xb == 0) {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_cam_reduce_xchg), RED_THREADS, red_shmem) != hipSuccess ||
+                hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+                return (int)hipErrorUnknown;
+            xb = std::min(XCHG_BLOCKS, per_cu * cus);
+            if (const char *e = getenv("GBP_XCHG_BLOCKS")) xb = std::max(1, std::min(xb, atoi(e)));
+            pl.xchg_blocks = xb;
+        }
         hipLaunchKernelGGL(k_cam_reduce_xchg, dim3(std::min(p.C, xb)), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial,
                            po, *merged, clk ? clk + 2 : nullptr);
         return (int)hipGetLastError();
