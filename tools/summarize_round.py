@@ -93,11 +93,13 @@ for size, F, L, C in (('1m', 1_000_000, 100_000, 500), ('10m', 10_000_000, 1_000
             if ts:
                 t["rocprofv3_trace_without_first_batch"] = ts
                 t["layout_frac_on_rocprofv3_steady_mean"] = line["roofline"]["bytes_per_launch"] / (ts["steady_mean_us"] * 1e3) / 8000.0 if line else None
+                t["layout_frac_on_rocprofv3_mean_without_first_batch"] = line["roofline"]["bytes_per_launch"] / (ts["mean_us"] * 1e3) / 8000.0 if line else None
             t["hbm_gbs_on_traffic"] = (fetch_b + write_b) / ka[0]
             t["frac_of_8tbs"] = (fetch_b + write_b) / ka[0] / 8000.0
         if line:
             t["layout_bytes_per_launch"] = line["roofline"]["bytes_per_launch"]
             t["bench_kernel_avg_us_device_clock"] = line["roofline"]["kernel_avg_ms"] * 1e3
+            t["bench_kernel_steady_us_device_clock"] = (line["roofline"].get("kernel_steady_ms") or 0.0) * 1e3
             t["bench_kernel_avg_us_hip_events_every_7th"] = (line["roofline"].get("kernel_event_ms") or 0.0) * 1e3
             t["bench_reduce_avg_us_device_clock"] = (line["roofline"].get("reduce_avg_ms") or 0.0) * 1e3
             t["bench_value_it_s"] = line["value"]
