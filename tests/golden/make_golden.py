@@ -258,7 +258,54 @@ def g9(ref):
          meas=prob.meas, cam_idx=prob.cam_idx, lmk_idx=prob.lmk_idx, **out)
 
 
-ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
+G12_STEPS = ['robustify_all_factors', 'relinearise_factors', 'compute_all_messages', 'update_all_beliefs', 'compute_all_factors',
+             'compute_all_messages', 'update_all_beliefs', 'relinearise_factors', 'relinearise_factors', 'compute_all_messages',
+             'update_all_beliefs']
+
+
+def g12(ref):
+    """The reference's stage-wise FactorGraph methods called one by one (gbp.py:46-84), in an order its own scripts never use: after 16
+    sweeps of ba.py's schedule on fr1desk_vsmall (loss huber, so that robustify does something; sweep 15 has relinearised everybody,
+    nobody is damped) every factor is allowed to relinearise again (iters_since_relin = 8) and the stages run in G12_STEPS order.
+    After EVERY call: all beliefs, and for every 7th factor its potential (eta, Lambda), linearisation point, adaptive variance,
+    robust flag, iters_since_relin, eta_damping and both messages."""
+    from gbp import gbp_ba
+    bal = os.path.join(HERE, 'data', 'fr1desk_vsmall.txt')
+    graph, _ = replay(gbp_ba, bal, 16, diagnostics=False, loss='huber')
+    for f in graph.factors:
+        f.iters_since_relin = 8
+    sub = np.arange(0, len(graph.factors), 7)
+    out = dict(factor_subset=sub, steps=np.array(G12_STEPS))
+
+    def snap(tag, k=0):
+        if k in (0, 4, 7, 11):                                    # (the beliefs only change in update_all_beliefs)
+            for name, arr in beliefs_of(graph).items():
+                out[f'{tag}_{name}'] = arr
+        fs = [graph.factors[i] for i in sub]
+        out[f'{tag}_factor_eta'] = np.array([f.factor.eta for f in fs])
+        if k in (0, 1, 2, 5, 8):                                  # (the potentials only change in these calls)
+            out[f'{tag}_factor_lam'] = np.array([f.factor.lam for f in fs])
+        out[f'{tag}_linpoint'] = np.array([np.asarray(f.linpoint, dtype=np.float64) for f in fs])
+        out[f'{tag}_adaptive_var'] = np.array([f.adaptive_gauss_noise_var for f in fs], dtype=np.float64)
+        out[f'{tag}_robust_flag'] = np.array([bool(f.robust_flag) for f in fs])
+        out[f'{tag}_iters_since_relin'] = np.array([f.iters_since_relin for f in fs], dtype=np.int32)
+        out[f'{tag}_eta_damping'] = np.array([f.eta_damping for f in fs], dtype=np.float64)
+        if k not in (0, 3, 6, 10):                                # (the messages only change in compute_all_messages)
+            return
+        out[f'{tag}_msg_cam_eta'] = np.array([f.messages[0].eta for f in fs])
+        out[f'{tag}_msg_cam_lam'] = np.array([f.messages[0].lam for f in fs])
+        out[f'{tag}_msg_lmk_eta'] = np.array([f.messages[1].eta for f in fs])
+        out[f'{tag}_msg_lmk_lam'] = np.array([f.messages[1].lam for f in fs])
+
+    snap('s0')
+    for k, name in enumerate(G12_STEPS):
+        getattr(graph, name)()
+        snap(f's{k + 1}', k + 1)
+    out['n_relinearised_first'] = sum(1 for f in graph.factors if f.iters_since_relin <= 3)
+    save('G12_stagewise_vsmall', **out)
+
+
+ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -238,3 +238,44 @@ def test_g9b_full_size_reference_beliefs(oracle_mod):
         if tag + 'iters_since_relin' in g:
             assert np.array_equal(st['iters_since_relin'][fs], g[tag + 'iters_since_relin'])
             assert np.array_equal(st['eta_damping'][fs], g[tag + 'eta_damping'])
+
+
+def test_g12_stagewise_calls_against_the_reference(oracle_mod):
+    """Fixture G12: the reference's stage-wise FactorGraph methods (gbp.py:46-84) called one by one in an order its scripts never use
+    (robustify / relinearise / messages / beliefs / compute_all_factors / ... two relinearise calls in a row), generated by
+    tests/golden/make_golden.py from the reference itself.  The oracle's stage functions -- the arbiter of tests/test_stagewise_gpu.py --
+    must reproduce every intermediate state: potentials, linearisation points, variances, flags, counters, damping after every call,
+    messages after every compute_all_messages, beliefs after every update_all_beliefs."""
+    g = golden('G12_stagewise_vsmall')
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    o = oracle_mod.OracleBA.from_problem(p, loss='huber', Nstds=3.0)
+    o.generate_priors_var(50.0)
+    o.update_all_beliefs()
+    oracle_mod.replay_ba(o, 16)
+    o.set_iters_since_relin(8)
+    sub = g['factor_subset']
+
+    def check(tag):
+        f, st = o.factors(), o.relin_state()
+        assert rel_err_rows(f['eta'][sub], g[tag + '_factor_eta']) < 1e-7, tag
+        if tag + '_factor_lam' in g:
+            assert rel_err_rows(f['lam'][sub], g[tag + '_factor_lam']) < 1e-7, tag
+        assert np.allclose(f['linpoint'][sub], g[tag + '_linpoint'], rtol=1e-8, atol=1e-10), tag
+        assert np.allclose(st['adaptive_var'][sub], g[tag + '_adaptive_var'], rtol=1e-9), tag
+        assert np.array_equal(st['robust_flag'][sub].astype(bool), g[tag + '_robust_flag']), tag
+        assert np.array_equal(st['iters_since_relin'][sub], g[tag + '_iters_since_relin']), tag
+        assert np.array_equal(st['eta_damping'][sub], g[tag + '_eta_damping']), tag
+        if tag + '_msg_cam_eta' in g:
+            m = o.messages()
+            for a, name in zip(m, ('msg_cam_eta', 'msg_cam_lam', 'msg_lmk_eta', 'msg_lmk_lam')):
+                assert rel_err_rows(a[sub], g[f'{tag}_{name}']) < 1e-6, (tag, name)
+        if tag + '_cam_eta' in g:
+            assert belief_gap(o.beliefs(), g, tag + '_') < 1e-7, tag
+
+    check('s0')
+    steps = [str(x) for x in g['steps']]
+    assert steps.count('compute_all_factors') == 1 and steps.count('relinearise_factors') == 3
+    for k, name in enumerate(steps):
+        getattr(o, name)()
+        check(f's{k + 1}')
+    assert int(g['n_relinearised_first']) > 1000

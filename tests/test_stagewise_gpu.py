@@ -175,3 +175,40 @@ def test_stagewise_needs_beliefs():
     for name in ('relinearise_factors', 'compute_all_messages', 'compute_all_factors'):
         with pytest.raises(GbpError):
             getattr(e, name)()
+
+
+def test_g12_stagewise_against_the_reference(oracle_mod):
+    """The same stage-wise sequence the reference itself ran for fixture G12 (tests/golden/make_golden.py: 16 sweeps of ba.py's
+    schedule with the Huber loss, then robustify / relinearise / messages / beliefs / compute_all_factors / ... two relinearise calls
+    in a row), on the device graph, against the REFERENCE's own intermediate states."""
+    from conftest import belief_gap, golden
+    from gbp_amd import engine as eng
+    g = golden('G12_stagewise_vsmall')
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    e = eng.BAEngine.from_problem(p, loss='huber', Nstds=3.0)
+    e.generate_priors_var(50.0)
+    e.update_all_beliefs()
+    oracle_mod.replay_ba(e, 16)
+    e.set_iters_since_relin(8)
+    sub = g['factor_subset']
+
+    def check(tag):
+        f, st = e.factors(), e.relin_state()
+        assert rel_err_rows(f['eta'][sub], g[tag + '_factor_eta']) < 1e-5, tag
+        if tag + '_factor_lam' in g:
+            assert rel_err_rows(f['lam'][sub], g[tag + '_factor_lam']) < 1e-5, tag
+        assert np.allclose(f['linpoint'][sub], g[tag + '_linpoint'], rtol=1e-6, atol=1e-6), tag
+        assert np.allclose(st['adaptive_var'][sub], g[tag + '_adaptive_var'], rtol=1e-6), tag
+        assert np.array_equal(st['robust_flag'][sub].astype(bool), g[tag + '_robust_flag']), tag
+        assert np.array_equal(st['iters_since_relin'][sub], g[tag + '_iters_since_relin']), tag
+        assert np.array_equal(st['eta_damping'][sub], g[tag + '_eta_damping']), tag
+        if tag + '_msg_cam_eta' in g:
+            for a, name in zip(e.messages(), ('msg_cam_eta', 'msg_cam_lam', 'msg_lmk_eta', 'msg_lmk_lam')):
+                assert rel_err_rows(a[sub], g[f'{tag}_{name}']) < 1e-5, (tag, name)
+        if tag + '_cam_eta' in g:
+            assert belief_gap(e.beliefs(), g, tag + '_') < 1e-6, tag
+
+    check('s0')
+    for k, name in enumerate(str(x) for x in g['steps']):
+        getattr(e, name)()
+        check(f's{k + 1}')
