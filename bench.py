@@ -4,21 +4,22 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one FactorGraph.synchronous_iteration(robustify=True, local_relin=True) (gbp/gbp.py:86-92) over the whole
-graph, inputs resident in HBM.  N > 1 shards the graph by landmark across N ranks, one process per GPU, one RCCL
-all-gather of the camera partial sums per iteration inside the library (gbp_ba_iterate_sharded); the total work is
-fixed, so scaling is "strong".  Started without torchrun, `--gpus N` spawns its own N ranks (re-exec under
+graph, inputs resident in HBM.  N > 1 shards the graph by landmark across N ranks, one process per GPU, one exchange of the
+camera partial sums per iteration inside the library (gbp_ba_iterate_sharded): an RCCL all-gather, or peer stores straight into
+the ranks' mailboxes over xGMI with no collective call (--exchange; the default measures both and reports the faster as `value`,
+the other beside it); the total work is fixed, so scaling is "strong".  Started without torchrun, `--gpus N` spawns its own N ranks (re-exec under
 torch.distributed.run on 127.0.0.1); started under torchrun it uses the ranks it is given.  Rank 0 prints ONE JSON line.
 
 Timing protocol.  Every batch starts from the same state -- the graph right after generate_priors_var +
 update_all_beliefs, restored from a device-resident checkpoint -- runs W untimed sweeps and then EXACTLY K timed sweeps bracketed by a
 barrier + device synchronisation on both sides (max over ranks).  Batches are repeated until >= 0.5 s have been timed;
 `value` = K / median batch time, the minimum is reported beside it.  One extra, untimed replay of the same batch is
-instrumented: every kernel of every sweep stamps the device's constant-rate clock (first workgroup in, last workgroup out --
-what rocprofv3 reports as the kernel's duration), HIP events bracket every 7th launch of the dominant kernel as a cross-check
-(an event pair also times the dispatch behind its barrier packet), and the device counts the factors that relinearise in each
+instrumented: workgroup 0 of every kernel of every sweep stores the device's constant-rate clock when it starts (consecutive start
+stamps tile the stream's timeline the way rocprofv3's kernel durations do); a further replay brackets every 7th launch of the
+dominant kernel with HIP events as a cross-check (an event pair also times the dispatch behind its barrier packet), and the device counts the factors that relinearise in each
 sweep: steady sweeps (fewer than 1 factor in 1000 relinearises: the case SURVEY 8d's byte count describes) and relinearising
-sweeps are reported separately.  N > 1 also prints per-rank device times (sweep / reduce / exchange / finish) and the rank
-count the exchange itself reports.
+sweeps are reported separately.  N > 1 also prints per-rank device times (sweep / reduce + exchange / finish / step) and the
+rank count the exchange itself reports.
 
 Roofline bookkeeping.  `roofline.achieved` = the bytes the engine's data layout MUST move per launch of the dominant
 kernel (F (21 read + 10 written doubles + 12 B of indices / state) + L (24 + 12 doubles) + one
