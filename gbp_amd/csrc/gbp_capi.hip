@@ -1624,7 +1624,7 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
-    hd.version = 4; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.version = 5; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
     hd.walk_parity = h->walk_parity; hd.reserved = 0;
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
     CHK(graph_hash(h, &hd.graph_hash));
@@ -1684,8 +1684,8 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
     if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0) return fail(GBP_EINVAL, "not a GBP state blob (magic)");
-    if (hd.version != 4)            // 1-3: dense / core-only message layouts of earlier builds -- not convertible without the Jacobians they were made with
-        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 4; INTEGRATION.md)", hd.version);
+    if (hd.version != 5)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances (records of 24 / 34 doubles)
+        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 5; INTEGRATION.md)", hd.version);
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)

@@ -62,10 +62,19 @@ namespace gbp {
 
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int TROW = 28;                            // doubles per row of the workgroup tables in HBM (27 + pad: 16-byte stores / loads)
-constexpr int WAT_WAVES = 8;
-constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][24] landmark records, then [64][9] messages
-constexpr int WAVE_PRIOR_DOUBLES = TILE_LMKS * LPRI;
-static_assert(TILE_LMKS * LREC <= WAVE_LDS_DOUBLES, "landmark records of a tile must fit the wave scratch");
+#ifndef GBP_WAT_WAVES
+#define GBP_WAT_WAVES 8
+#endif
+constexpr int WAT_WAVES = GBP_WAT_WAVES;            // two waves per SIMD.  Round 4 built the three-waves-per-SIMD variant the covariance-form
+                                                    // factor core makes possible (-DGBP_WAT_WAVES=12: <= 168 VGPRs, twelve [64][9] message
+                                                    // scratches beside a 500-camera table) and measured it SLOWER on MI355X: 118 us per sweep
+                                                    // with the relinearisation path in the kernel (55 registers spilled), 99-102 us without it
+                                                    // (9 spilled, nothing in the loop) against 66.8 us for eight waves -- every phase that
+                                                    // only issues vector-memory instructions takes twice as long, and the slowest workgroup
+                                                    // finishes 33 % after the mean (profiles/r04_waves12_*.txt).  The CU's memory pipeline is
+                                                    // the limit; more waves queue in front of it.
+constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][10] landmark heads (mean | covariance | rows), then [64][9] messages
+static_assert(TILE_LMKS * LHEAD <= WAVE_LDS_DOUBLES, "landmark heads of a tile must fit the wave scratch");
 
 struct FusedArgs {
     double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes
@@ -107,28 +116,29 @@ constexpr int NPHASE = 12;
 #endif
 
 
-// A/B switches for the factor streams of the fused sweep (tools/ab_nt.sh builds the variants): nontemporal loads / stores
-#ifdef GBP_NT_LOADS
-#define GBP_LD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define GBP_LD(ptr) (*(ptr))
-#endif
-#ifdef GBP_NT_STORES
-#define GBP_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#else
-#define GBP_ST(ptr, v) (*(ptr) = (v))
-#endif
+// Accesses of the persistent loop: a wave-uniform base pointer (SGPR pair) + an unsigned 32-bit lane offset, so that the address of
+// a load or store costs ONE vector register (global_load ... v_off, s[base:base+1]) instead of a 64-bit pair per access -- with
+// per-access 64-bit addresses the loop kept ~30 address registers alive (or spilled them) between a tile's loads and its stores.
+// (Nontemporal loads / stores for the streams were measured in round 3 and lost: +12...18 us, they bypass the memory-side cache.)
+// (the offset is in BYTES and 32 bits wide: base + zext(offset) is the one address shape the saddr form of global_load takes)
+GBP_DEV double2 ld2(const double *__restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+GBP_DEV void st2(double *__restrict__ base, unsigned byte_off, double x, double y)
+{
+    *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + byte_off) = make_double2(x, y);
+}
+GBP_DEV void st1(double *__restrict__ base, unsigned byte_off, double x) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off) = x; }
 
 template <int LOSS, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles,
-                                                                          const int *__restrict__ blk_begin)
+__global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles, const int *__restrict__ blk_begin)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *acc = smem;                                              // [C][27]
     const int acc_even = (a.acc_doubles + 1) & ~1, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *wl = smem + acc_even + wave * WAVE_LDS_DOUBLES;
-    double *wp = smem + acc_even + NWAVES * WAVE_LDS_DOUBLES + wave * WAVE_PRIOR_DOUBLES;      // [24][10] prior | rows
-    int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES));   // {next, done}
+    int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * WAVE_LDS_DOUBLES);   // {next, done}
     const int tid = threadIdx.x, lane = tid & 63;
     clk_begin(a.clk);
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
@@ -137,15 +147,27 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
     const int tb = blk_begin[blockIdx.x], ntl = blk_begin[blockIdx.x + 1] - tb;
 
     // The landmark beliefs of a tile (LDS work, no loads) are formed one iteration LATE, after the next tile's loads have
-    // been issued, so that the wave has HBM requests in flight meanwhile.  Nothing is carried in vector registers: the
-    // tile's landmark messages and priors wait in the wave's LDS scratch, which the next tile overwrites only afterwards.
+    // been issued, so that the wave has HBM requests in flight meanwhile.  The tile's landmark messages wait in the wave's LDS
+    // scratch, which the next tile overwrites only afterwards; the priors they are added to (one entry per lane and pass) and the
+    // landmarks' slot ranges are fetched at the end of the tile's own iteration and wait in nine registers.
     bool pend = false;
-    int q_t = 0, q_l0 = 0, q_nl = 0;
+    int q_l0 = 0, q_nl = 0;
+    LmkPre pre;
+#pragma unroll
+    for (int b = 0; b < LMK_PASSES; ++b) pre.pri[b] = 0.0;
+    pre.rows = 0;
     int n_relin = 0;                                      // factors of this wave's tiles that relinearised (wave-uniform)
     GBP_PH_DECL;
 
+    const int lane_entry = lane;
     for (;;) {
         GBP_PH_NOWAIT(9);                                  // loop overhead / after the release of the accumulation ticket
+        // Everything the loop derives from the lane index (LDS offsets of the belief phase, stream offsets, ...) is two or three
+        // integer instructions away from it; hoisted out of the persistent loop -- which is what the compiler does with loop
+        // invariants -- they occupied (and spilled) ~30 vector registers.  An opaque copy per iteration keeps them local.
+        int lane = lane_entry;
+        asm volatile("" : "+v"(lane));
+        lane &= 63;
         int ti = 0;
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
@@ -155,107 +177,108 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         if (valid) td = tiles[t];
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
-        const int slot = t * WTILE + lane;
         GBP_PH(0);                                         // ticket + descriptor
         if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
-            if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, wp, lane, q_t, q_l0, q_nl);
+            if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
             GBP_PH_NOWAIT(2);
             break;
         }
 
-        // the tile's landmark records (belief | mean | prior | rows) are one contiguous run: the wave fetches it whole
-        const int nrec2 = max(nl, 1) * (LREC / 2);         // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
+        // the heads (mean | covariance | rows) of the tile's landmark records: ten doubles of every thirty, fetched by the whole wave
+        const int nhead2 = max(nl, 1) * (LHEAD / 2);       // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
         const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
-        constexpr int NSTAGE = (WAVE_LDS_DOUBLES / 2 + 63) / 64;
+        constexpr int NSTAGE = (TILE_LMKS * (LHEAD / 2) + 63) / 64;
         double2 stage[NSTAGE];
 #pragma unroll
-        for (int j = 0; j < NSTAGE; ++j) stage[j] = (j * 64 + lane < nrec2) ? lsrc[j * 64 + lane] : make_double2(0.0, 0.0);
+        for (int j = 0; j < NSTAGE; ++j) {
+            const int i = j * 64 + lane, rec = (i * 205) >> 10, piece = i - rec * (LHEAD / 2);    // i / 5, exact for i < 128
+            stage[j] = i < nhead2 ? lsrc[rec * (LREC / 2) + piece] : make_double2(0.0, 0.0);
+        }
 
-        // everything the factor streams
+        // everything the factor streams: six + five row pairs of the tile's block, 16 bytes per lane each
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], etaC[6], clC[21];
-        const unsigned meta = p.meta[slot];
-        int st = p.state[slot];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x0[k] = GBP_LD(&p.lin[lin_at(slot, ROW_X0 + k)]);
-        z[0] = GBP_LD(&p.lin[lin_at(slot, ROW_Z)]); z[1] = GBP_LD(&p.lin[lin_at(slot, ROW_Z + 1)]);
-        if (LOSS != 0) avar = GBP_LD(&p.lin[lin_at(slot, ROW_AVAR)]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { qC[k] = GBP_LD(&p.msg[msg_at(slot, ROW_QC + k)]); qL[k] = GBP_LD(&p.msg[msg_at(slot, ROW_QL + k)]); }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) WC[k] = GBP_LD(&p.msg[msg_at(slot, ROW_WC + k)]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) VL[k] = GBP_LD(&p.msg[msg_at(slot, ROW_VL + k)]);
+        const double *lin_t = p.lin + (size_t)t * (LIN_ROWS * WTILE);
+        const double *msg_t = p.msg + (size_t)t * (MSG_ROWS * WTILE);
+        const unsigned lo = (unsigned)lane * 16u;         // byte offset of this lane's 16 bytes inside a row pair (1 KB per pair)
+        double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
+        const unsigned meta = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.meta + (size_t)t * WTILE) + (unsigned)lane * 4u);
+        int st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u);
+        {
+            const double2 a0 = ld2(lin_t, lo), a1 = ld2(lin_t, 1024u + lo), a2 = ld2(lin_t, 2048u + lo), a3 = ld2(lin_t, 3072u + lo),
+                          a4 = ld2(lin_t, 4096u + lo), a5 = ld2(lin_t, 5120u + lo);
+            const double2 m0 = ld2(msg_t, lo), m1 = ld2(msg_t, 1024u + lo), m2 = ld2(msg_t, 2048u + lo), m3 = ld2(msg_t, 3072u + lo),
+                          m4 = ld2(msg_t, 4096u + lo);
+            x0[0] = a0.x; x0[1] = a0.y; x0[2] = a1.x; x0[3] = a1.y; x0[4] = a2.x; x0[5] = a2.y; x0[6] = a3.x; x0[7] = a3.y;
+            x0[8] = a4.x; z[0] = a4.y; z[1] = a5.x;
+            if (LOSS != 0) avar = a5.y;
+            qC[0] = m0.x; qC[1] = m0.y; qL[0] = m1.x; qL[1] = m1.y;
+            WC[0] = m2.x; WC[1] = m2.y; WC[2] = m3.x; VL[0] = m3.y; VL[1] = m4.x; VL[2] = m4.y;
+        }
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
         // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
-        if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, wp, lane, q_t, q_l0, q_nl);
+        if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(2);                                  // landmark beliefs of the previous tile (LDS)
 
         // the camera record of this tile's factors: a gather that needs `meta` (L2 hits)
         const int cam = active ? (int)(meta >> META_LMK_BITS) : 0;
         GBP_PH(3);                                         // the streams (and meta) have arrived
-        load_cam_record(p.cbel + (size_t)((a.dbg & 8) ? (cam & 7) : cam) * CAMREC, etaC, clC, muC);   // (dbg 8: what would a cheap gather buy?)
+        {
+            const unsigned co = (unsigned)((a.dbg & 8) ? (cam & 7) : cam) * (unsigned)(CAMREC * 8);      // (dbg 8: what would a cheap gather buy?)
+            double v[CAMHEAD];
+#pragma unroll
+            for (int i = 0; i < CAMHEAD / 2; ++i) { const double2 t2 = ld2(p.cbel, co + 16u * i); v[2 * i] = t2.x; v[2 * i + 1] = t2.y; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) muC[i] = v[CAM_MU + i];
+#pragma unroll
+            for (int i = 0; i < 21; ++i) PC[i] = v[CAM_COV + i];
+        }
         asm volatile("" ::: "memory");
         GBP_PH(4);                                         // camera gather
 
-        // landmark records -> wave scratch -> the lanes of their factors; priors | rows -> wp for the tail
+        // landmark heads -> wave scratch -> the lanes of their factors
 #pragma unroll
         for (int j = 0; j < NSTAGE; ++j)
-            if (j * 64 + lane < WAVE_LDS_DOUBLES / 2) reinterpret_cast<double2 *>(wl)[j * 64 + lane] = stage[j];
-        wave_lds_sync();
-        double muL[3], clL[6];
-        if (active) {
-            const double *src = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) clL[k] = src[LR_BEL + 3 + k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) muL[k] = src[LR_MU + k];
-        }
-        if (lane < nl) {                                   // prior | rows of the tile's landmarks, kept for the tail
-            int o = lane;
-            asm volatile("" : "+v"(o));                    // (keeps the compiler from hoisting five addresses out of the loop and spilling them)
-            const double2 *src = reinterpret_cast<const double2 *>(wl + o * LREC + LR_PRIOR);
-            double2 *dst = reinterpret_cast<double2 *>(wp + o * LPRI);
-#pragma unroll
-            for (int k = 0; k < LPRI / 2; ++k) dst[k] = src[k];
-        }
+            if (j * 64 + lane < TILE_LMKS * (LHEAD / 2)) reinterpret_cast<double2 *>(wl)[j * 64 + lane] = stage[j];
         wave_lds_sync();
         GBP_PH_NOWAIT(5);                                  // landmark records through LDS
 
         double MCn[21], eC[6];
         if (active) {
-            double MLn[6], eL[3];
-            const double *lbel = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LREC + LR_BEL;   // still intact: messages go in below
+            double MLn[6], eL[3], muL[3];
+            const double *lhead = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LHEAD;     // intact until the messages go in below
+#pragma unroll
+            for (int k = 0; k < 3; ++k) muL[k] = lhead[LR_MU + k];
             Params q = p;
             pin_scalars(q);
-            const bool relin = factor_core<LOSS, false>(q, x0, z, st, avar, muC, muL, etaC, clC,
-                                                        [lbel](double (&e)[3]) { e[0] = lbel[0]; e[1] = lbel[1]; e[2] = lbel[2]; },
-                                                        clL, qC, qL, WC, VL, eC, eL, MCn, MLn);
+            double *lin_w = p.lin + (size_t)t * (LIN_ROWS * WTILE), *msg_w = p.msg + (size_t)t * (MSG_ROWS * WTILE);
+            const bool relin = factor_core<LOSS, false>(q, x0, z, st, avar, muC, PC, muL,
+                                                        [lhead](double (&c)[6]) {
+#pragma unroll
+                                                            for (int k = 0; k < 6; ++k) c[k] = lhead[LR_COV + k];
+                                                        },
+                                                        [lin_w, lo](const double (&x)[9]) {
+                                                            st2(lin_w, lo, x[0], x[1]); st2(lin_w, 1024u + lo, x[2], x[3]);
+                                                            st2(lin_w, 2048u + lo, x[4], x[5]); st2(lin_w, 3072u + lo, x[6], x[7]);
+                                                            st1(lin_w, 4096u + lo, x[8]);
+                                                        },
+                                                        qC, qL, WC, VL, eC, eL, MCn, MLn);
             n_relin += relin_in_wave(relin);
             GBP_PH_NOWAIT(6);                              // the maths
-            int sslot = slot;
-            asm volatile("" : "+v"(sslot));             // store addresses are recomputed here, not kept alive (and spilled) through the maths
-            if (relin) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) p.lin[lin_at(sslot, ROW_X0 + k)] = x0[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) { GBP_ST(&p.msg[msg_at(sslot, ROW_QC + k)], qC[k]); GBP_ST(&p.msg[msg_at(sslot, ROW_QL + k)], qL[k]); }
+            st2(msg_w, lo, qC[0], qC[1]); st2(msg_w, 1024u + lo, qL[0], qL[1]);
+            wave_lds_sync();                               // every lane of the tile has read its landmark head
 #pragma unroll
             for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) GBP_ST(&p.msg[msg_at(sslot, ROW_WC + k)], WC[k]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) GBP_ST(&p.msg[msg_at(sslot, ROW_VL + k)], VL[k]);
+            st2(msg_w, 2048u + lo, WC[0], WC[1]); st2(msg_w, 3072u + lo, WC[2], VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-            p.state[sslot] = st;
-            if (LOSS != 0) p.lin[lin_at(sslot, ROW_AVAR)] = avar;
+            *reinterpret_cast<int *>(reinterpret_cast<char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u) = st;
+            if (LOSS != 0) st1(lin_w, 5120u + lo + 8u, avar);
         }
+        lmk_prefetch(p, lane, t, l0, nl, pre);             // priors | slot ranges for this tile's belief phase, one iteration from now
         wave_lds_sync();
         GBP_PH_NOWAIT(7);                                  // stores issued
         // camera accumulation strictly in tile order
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void k_sweep_wat(Params p,
         }
         wave_lds_sync();
         if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pend = true; q_t = t; q_l0 = l0; q_nl = nl;
+        pend = true; q_l0 = l0; q_nl = nl;
     }
     if (lane == 0) relin_add(p, n_relin);
     GBP_PH_NOWAIT(9);
@@ -413,16 +436,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
     if (tid >= 64 && tid < 64 + 27) rec[CAM_ETA + tid - 64] = tot[tid - 64];      // eta | Lambda: one store instruction of another wave
-    if (tid == 0) {
-        double eta[6], lam[21], mu[6];
+    if (tid < 7) {                                          // mean and the six columns of the covariance, one lane each
+        double v[27];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eta[k] = tot[k];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) lam[k] = tot[6 + k];
-        spd_solve<6>(lam, eta, mu);
-        double2 *r2 = reinterpret_cast<double2 *>(rec + CAM_MU);
-        r2[0] = make_double2(mu[0], mu[1]); r2[1] = make_double2(mu[2], mu[3]); r2[2] = make_double2(mu[4], mu[5]);
-        rec[33] = 0.0;
+        for (int k = 0; k < 27; ++k) v[k] = tot[k];
+        cam_belief_store(v, rec, tid);
     }
 }
 
@@ -522,7 +540,7 @@ inline int fused_upload(FusedPlan &pl, T **dst, const T *src, size_t n, hipStrea
 inline size_t fused_shmem(int C)
 {
     const int acc_doubles = C * 27;
-    return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * (WAVE_LDS_DOUBLES + WAVE_PRIOR_DOUBLES) + 2);
+    return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * WAVE_LDS_DOUBLES + 1);
 }
 
 // most cameras one k_cam_pass launch adds up: its table and two control words are all it keeps in the LDS

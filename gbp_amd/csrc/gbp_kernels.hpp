@@ -23,10 +23,12 @@
 // Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt from x0 and z
 // every sweep (2x9 Jacobian ~ 150 flops versus 720 bytes of traffic).
 //
-// Landmarks: array of records lrec[L][24] = belief (eta 3 | Lambda 6) | mu 3 | prior (eta 3 | Lambda 6) |
-//            {first slot, end slot} as two int32 | pad.  A tile's landmarks are consecutive records.
-// Cameras:   cbel[C][34] = mu 6 | eta 6 | Lambda 21 | pad (gathered per factor, L2-resident: 500 cams = 136 KB),
-//            cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of each camera's factors (reference order).
+// A factor reads a belief as MEAN | COVARIANCE (gbp_math.hpp: covariance form); eta | Lambda are kept beside them for the views.
+// Landmarks: array of records lrec[L][30] = mu 3 | Sigma 6 | {first slot, end slot} as two int32 | prior (eta 3 | Lambda 6) | pad |
+//            belief (eta 3 | Lambda 6) | pad.  A tile's landmarks are consecutive records.
+// Cameras:   cbel[C][56] = mu 6 | Sigma 21 | pad | eta 6 | Lambda 21 | pad (the first 224 bytes are gathered per factor,
+//            L2-resident: 500 cams = 112 KB), cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of each camera's
+//            factors (reference order).
 //
 // General sweep (any shape) = k_factor_tile (one wave per tile: messages, the tile's landmark beliefs, camera messages
 // staged in camera-major order) -> k_lmk_belief_list (landmarks larger than a tile) -> k_cam_partial_staged (one
@@ -43,10 +45,12 @@ constexpr int LIN_ROWS = 12, MSG_ROWS = 10;
 constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_AVAR = 11;
 constexpr int ROW_QC = 0, ROW_QL = 2, ROW_WC = 4, ROW_VL = 7;
 constexpr int XTRA_ROW = 9;       // doubles per slot of the dense remainder (num_undamped_iters = 0 only): camera 6 | landmark 3
-constexpr int LREC = 24;          // doubles per landmark record
-constexpr int LR_BEL = 0, LR_MU = 9, LR_PRIOR = 12, LR_ROWS = 21;
-constexpr int CAMREC = 34;        // doubles per camera record
-constexpr int CAM_MU = 0, CAM_ETA = 6, CAM_LAM = 12;
+constexpr int LREC = 30;          // doubles per landmark record: mu 3 | Sigma 6 | rows | prior 9 | pad | belief 9 | pad
+constexpr int LR_MU = 0, LR_COV = 3, LR_ROWS = 9, LR_PRIOR = 10, LR_BEL = 20;
+constexpr int LHEAD = 10;         // ... of which a factor reads the first ten (mean | covariance | rows)
+constexpr int CAMREC = 56;        // doubles per camera record: mu 6 | Sigma 21 | pad | eta 6 | Lambda 21 | pad
+constexpr int CAM_MU = 0, CAM_COV = 6, CAM_ETA = 28, CAM_LAM = 34;
+constexpr int CAMHEAD = 28;       // ... of which a factor gathers the first 28 (mean | covariance): 14 x 16 bytes
 constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (camera in the LOW bits + '& 0xffffff' was
                                    // miscompiled by hipcc 7.2: the mask vanished in front of a v_mad_u64_u32 address multiply)
 constexpr int BLOCK = 256;
@@ -105,9 +109,9 @@ constexpr int STATE_SHIFT = 12;
 constexpr int ITERS_MAX = (1 << (31 - STATE_SHIFT)) - 1;     // iters_since_relin saturates here (524 287)
 constexpr unsigned STATE_RANK_MASK = 0x1ffu;
 constexpr int STATE_PENDING = 1 << 11;
-GBP_DEV int state_iters(int st) { return st >> STATE_SHIFT; }
-GBP_DEV int state_rank(int st) { return (st >> 2) & (int)STATE_RANK_MASK; }
-GBP_DEV int state_pack(int iters, int rank, bool robust, bool damped, bool pending = false)
+GBP_HD int state_iters(int st) { return st >> STATE_SHIFT; }
+GBP_HD int state_rank(int st) { return (st >> 2) & (int)STATE_RANK_MASK; }
+GBP_HD int state_pack(int iters, int rank, bool robust, bool damped, bool pending = false)
 {
     return (int)(((unsigned)iters << STATE_SHIFT) | (pending ? (unsigned)STATE_PENDING : 0u) | ((unsigned)rank << 2) | (robust ? 2u : 0u) | (damped ? 1u : 0u));
 }
@@ -117,7 +121,7 @@ GBP_DEV int state_pack(int iters, int rank, bool robust, bool damped, bool pendi
 // means; `d` is the eta damping for this sweep.  x0 is NOT modified here (the old point is still needed to rebuild the
 // factor's old messages).
 template <int LOSS>
-GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double (&z)[2], int &st, double &avar,
+GBP_HD bool factor_decide(const Params &p, const double (&x0)[9], const double (&z)[2], int &st, double &avar,
                            const double (&muC)[6], const double (&muL)[3], double &d)
 {
     int iters = state_iters(st);
@@ -162,7 +166,7 @@ GBP_DEV bool factor_decide(const Params &p, const double (&x0)[9], const double 
 }
 
 // Factor.compute_factor in compact form (gbp.py:267-294): J = [Jc | Jl], rho = J x0 + z - h(x0), s = 1 / adaptive var
-GBP_DEV void factor_linearise(const Params &p, const double (&x0)[9], const double (&z)[2], double avar, double d, Lin &L)
+GBP_HD void factor_linearise(const Params &p, const double (&x0)[9], const double (&z)[2], double avar, double d, Lin &L)
 {
     L.d = d;
     L.s = rcp(avar);
@@ -179,87 +183,88 @@ GBP_DEV void factor_linearise(const Params &p, const double (&x0)[9], const doub
     }
 }
 
-// One factor's sweep in registers (gbp.py:82-84, 64-80, 46-54, 334-373).
-//   in : x0, z, state, adaptive variance, means of the two beliefs,
-//        etaC = eta_C, clC = Lambda_C (camera belief),  lmk_belief_eta(out[3]) yields eta_L when it is needed, clL = Lambda_L
-//        (cl* are consumed),
+// One factor's sweep in registers (gbp.py:82-84, 64-80, 46-54, 334-373), covariance form (gbp_math.hpp header).
+//   in : x0, z, state, adaptive variance,
+//        muC | PC = mean | covariance of the camera belief, muL = mean of the landmark belief, load_PL(PL) yields its covariance,
 //        old message coefficients qC / qL and old cores WC / VL
 //   out: new qC / qL / WC / VL (both messages from the OLD ones, gbp.py:371-373), dense new etas eCn / eLn and Lambdas
-//        MCn / MLn for the belief sums, x0 / state / avar updated; returns true when the factor relinearised (x0 changed).
+//        MCn / MLn for the belief sums, state / avar updated; returns true when the factor relinearised: store_x0(x0) has then been
+//        called with the new linearisation point.  (x0, muC, PC, muL are scratch.)
 //   XTRA: xt = this slot's dense remainder (read and updated), see Params::xtra.
-template <int LOSS, bool XTRA, typename LmkEta>
-GBP_DEV bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
-                         const double (&muC)[6], const double (&muL)[3],
-                         const double (&etaC)[6], double (&clC)[21], LmkEta &&lmk_belief_eta, double (&clL)[6],
-                         double (&qC)[2], double (&qL)[2], double (&WC)[3], double (&VL)[3],
-                         double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr)
+template <int LOSS, bool XTRA, typename LmkCov, typename StoreX0>
+GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
+                        double (&muC)[6], double (&PC)[21], double (&muL)[3], LmkCov &&load_PL, StoreX0 &&store_x0,
+                        double (&qC)[2], double (&qL)[2], double (&WC)[3], double (&VL)[3],
+                        double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr)
 {
     double d;
+#ifdef GBP_EXPERIMENT_NO_RELIN_PATH                          // timing experiment only (wrong results in relinearising sweeps)
+    const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d) && false;
+#else
     const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
+#endif
     Lin L;
     factor_linearise(p, x0, z, avar, d, L);
-    // Each elimination works on  belief - this factor's OLD message + the factor's own block.  The old message lives in the span
-    // of the OLD Jacobian (M = J^T Q J, e = J^T q).  A factor that keeps its linearisation point -- every factor of most sweeps --
-    // folds the two terms:  Lambda_C - Jc^T W Jc + s Jc^T Jc = Lambda_C + Jc^T (sI - W) Jc  and  eta_C - Jc^T q + s Jc^T rho =
-    // eta_C + Jc^T (s rho - q): one rank-2 update per block instead of two.  One that relinearises (or carries a dense
-    // remainder) takes the old message out first, with the old Jacobian.
-    const bool two_step = XTRA || relin;
-    double uC[6], eLold[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) uC[i] = etaC[i];
+    double PL[6];
+    load_PL(PL);
+    double dqC[2] = {d * qC[0], d * qC[1]}, dqL[2] = {d * qL[0], d * qL[1]};      // the old etas' share of the new ones (gbp.py:368)
     double xn[XTRA ? XTRA_ROW : 1];
-    if (two_step) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) uC[i] -= L.Jc[0][i] * qC[0] + L.Jc[1][i] * qC[1];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) eLold[i] = L.Jl[0][i] * qL[0] + L.Jl[1][i] * qL[1];
-        rank2_update<6>(clC, L.Jc[0], L.Jc[1], WC, -1.0);
-        rank2_update<3>(clL, L.Jl[0], L.Jl[1], VL, -1.0);
-        if (XTRA) {
-            // e_old = J_old^T q_old + x_old.  Damped in the very sweep it relinearises: d e_old leaves the span of the new
-            // Jacobian and is carried densely; otherwise only the old remainder decays.
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double eo = etaC[i] - uC[i] + xt[i];             // the old dense message to the camera
-                uC[i] -= xt[i];
-                xn[i] = relin ? d * eo : d * xt[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                eLold[i] += xt[6 + i];
-                xn[6 + i] = relin ? d * eLold[i] : d * xt[6 + i];
-            }
-            if (relin) { qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0; }
-        }
-        if (relin) {                                       // gbp.py:75-78: linearise again at the belief means
+    // A factor that keeps its linearisation point -- every factor of most sweeps -- eliminates straight from the beliefs: its old
+    // message has the Jacobian of its new block, so belief - old message + own block is ONE rank-2 update (Q = s I - W).  One that
+    // relinearises (or carries a dense remainder) takes the old message out of the beliefs first, with the old Jacobian (in place:
+    // mu | P become the cavity's), and then runs the same elimination with no old message at the new point.
+    if (XTRA || relin) {
+        if (relin) {                                       // gbp.py:75-78: the new linearisation point = the belief means
 #pragma unroll
             for (int i = 0; i < 6; ++i) x0[i] = muC[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
-            factor_linearise(p, x0, z, avar, d, L);
+            store_x0(x0);                                  // at once: the stores' operands do not travel through the eliminations
         }
-    }
-    // the factor's own block (minus the folded old message): cores of the rank-2 terms and coefficients of the eta terms
-    const double s = L.s;
-    double cW[3] = {s, 0.0, s}, cV[3] = {s, 0.0, s}, rC[2] = {s * L.rho[0], s * L.rho[1]}, rL[2] = {rC[0], rC[1]};
-    if (!two_step) {
-        cW[0] -= WC[0]; cW[1] -= WC[1]; cW[2] -= WC[2];
-        cV[0] -= VL[0]; cV[1] -= VL[1]; cV[2] -= VL[2];
-        rC[0] -= qC[0]; rC[1] -= qC[1];
-        rL[0] -= qL[0]; rL[1] -= qL[1];
-    }
-    rank2_update<6>(clC, L.Jc[0], L.Jc[1], cW, 1.0);
+        downdate<3>(PL, muL, L.Jl[0], L.Jl[1], VL, qL);
+        downdate<6>(PC, muC, L.Jc[0], L.Jc[1], WC, qC);
+        if (XTRA) {
+            // e_old = J_old^T q_old + x_old: the remainder leaves the cavity too (mu' -= P' x_old).  Damped in the very sweep it
+            // relinearises: d e_old leaves the span of the new Jacobian and is carried densely; otherwise only the old remainder decays.
+            double xo[9];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) uC[i] += L.Jc[0][i] * rC[0] + L.Jc[1][i] * rC[1];
-    double qLn[2];
-    message_to_landmark(L, uC, clC, qL, qLn, eLn, MLn, VL);
-    double gL[3];                                          // fetched only now: three doubles less through the 6x6 elimination
-    lmk_belief_eta(gL);
-    rank2_update<3>(clL, L.Jl[0], L.Jl[1], cV, 1.0);
+            for (int i = 0; i < 9; ++i) xo[i] = xt[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gL[i] += L.Jl[0][i] * rL[0] + L.Jl[1][i] * rL[1] - eLold[i];
-    message_to_camera(L, gL, clL, qC, eCn, MCn, WC);
-    qL[0] = qLn[0]; qL[1] = qLn[1];
+            for (int i = 0; i < 6; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) a += PC[i <= j ? Sym<6>::at(i, j) : Sym<6>::at(j, i)] * xo[j];
+                muC[i] -= a;
+                xn[i] = relin ? d * (jcomb<6>(i, qC[0], qC[1], L.Jc[0], L.Jc[1]) + xo[i]) : d * xo[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a += PL[i <= j ? Sym<3>::at(i, j) : Sym<3>::at(j, i)] * xo[6 + j];
+                muL[i] -= a;
+                xn[6 + i] = relin ? d * (L.Jl[0][i] * qL[0] + L.Jl[1][i] * qL[1] + xo[6 + i]) : d * xo[6 + i];
+            }
+        }
+        if (relin) {
+            factor_linearise(p, x0, z, avar, d, L);
+            // the in-span part of the old eta lives in the rows of the OLD Jacobian: it cannot be mixed into the new coefficients
+            // (d is 0 here, or -- XTRA -- the old eta travels in the remainder xn)
+            dqC[0] = 0.0; dqC[1] = 0.0; dqL[0] = 0.0; dqL[1] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { WC[k] = 0.0; VL[k] = 0.0; }
+        qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0;
+    }
+    double Vn[3], Wn[3], rL[2], rC[2];
+    eliminate<3>(PL, muL, L.Jl[0], L.Jl[1], VL, qL, L.rho, L.s, Wn, rC);      // landmark out: the message to the camera
+    eliminate<6>(PC, muC, L.Jc[0], L.Jc[1], WC, qC, L.rho, L.s, Vn, rL);      // camera out: the message to the landmark
+    qL[0] = (1.0 - d) * rL[0] + dqL[0]; qL[1] = (1.0 - d) * rL[1] + dqL[1];
+    qC[0] = (1.0 - d) * rC[0] + dqC[0]; qC[1] = (1.0 - d) * rC[1] + dqC[1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { VL[k] = Vn[k]; WC[k] = Wn[k]; }
+    dense_message<3>(L.Jl[0], L.Jl[1], qL, VL, eLn, MLn);
+    dense_message<6>(L.Jc[0], L.Jc[1], qC, WC, eCn, MCn);
     if (XTRA) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { eCn[i] += xn[i]; xt[i] = xn[i]; }
@@ -284,18 +289,44 @@ GBP_DEV void relin_add(const Params &p, int n)                                  
 // rebuilt from their coefficients / cores at the stored linearisation point.
 GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (&MC)[21], double (&eL)[3], double (&ML)[6]);
 
-GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&eta)[6], double (&lam)[21], double (&mu)[6])
+// the part of a camera record a factor reads: mean | covariance, 14 x 16 bytes
+GBP_DEV void load_cam_record(const double *__restrict__ rec, double (&mu)[6], double (&cov)[21])
 {
     const double2 *r2 = reinterpret_cast<const double2 *>(rec);
-    double v[34];
+    double v[CAMHEAD];
 #pragma unroll
-    for (int i = 0; i < 17; ++i) { const double2 t = r2[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+    for (int i = 0; i < CAMHEAD / 2; ++i) { const double2 t = r2[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
 #pragma unroll
     for (int i = 0; i < 6; ++i) mu[i] = v[CAM_MU + i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) eta[i] = v[CAM_ETA + i];
+    for (int i = 0; i < 21; ++i) cov[i] = v[CAM_COV + i];
+}
+
+// A camera belief from its eta | Lambda (v, the same 27 values in every participating lane), written in both forms.  Lanes 0..6 of
+// a wave: lane c < 6 solves Lambda x = e_c (column c of the covariance), lane 6 solves Lambda mu = eta -- seven lanes instead of one
+// lane doing seven solves in a row (VariableNode.update_belief gbp.py:189-193, plus the inverse the factors read, gbp_math.hpp).
+GBP_DEV void cam_belief_store(const double (&v)[27], double *__restrict__ rec, int lane)
+{
+    if (lane >= 7) return;
+    double lam[21], invd[6], e[6];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) lam[i] = v[CAM_LAM + i];
+    for (int k = 0; k < 21; ++k) lam[k] = v[6 + k];
+    ldl_factor<6>(lam, invd);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = lane == 6 ? v[i] : (i == lane ? 1.0 : 0.0);
+    ldl_forward<6>(lam, e);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] *= invd[i];
+    ldl_backward<6>(lam, e);
+    if (lane == 6) {
+        double2 *r2 = reinterpret_cast<double2 *>(rec + CAM_MU);
+        r2[0] = make_double2(e[0], e[1]); r2[1] = make_double2(e[2], e[3]); r2[2] = make_double2(e[4], e[5]);
+        rec[CAM_COV + 21] = 0.0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i <= lane) rec[CAM_COV + i * 6 - (i * (i - 1)) / 2 + (lane - i)] = e[i];
+    }
 }
 
 // slot -> (valid, camera, landmark) through the tile table and the meta word
@@ -321,19 +352,15 @@ GBP_DEV void dense_messages(const Params &p, int slot, double (&eC)[6], double (
     for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
     for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
+    dense_message<6>(Jc[0], Jc[1], qC, WC, eC, MC);
+    dense_message<3>(Jl[0], Jl[1], qL, VL, eL, ML);
+    if (p.xtra) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) eC[k] = Jc[0][k] * qC[0] + Jc[1][k] * qC[1] + (p.xtra ? p.xtra[(size_t)slot * XTRA_ROW + k] : 0.0);
+        for (int k = 0; k < 6; ++k) eC[k] += p.xtra[(size_t)slot * XTRA_ROW + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) eL[k] = Jl[0][k] * qL[0] + Jl[1][k] * qL[1] + (p.xtra ? p.xtra[(size_t)slot * XTRA_ROW + 6 + k] : 0.0);
-#pragma unroll
-    for (int k = 0; k < 21; ++k) MC[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ML[k] = 0.0;
-    rank2_update<6>(MC, Jc[0], Jc[1], WC, 1.0);
-    rank2_update<3>(ML, Jl[0], Jl[1], VL, 1.0);
+        for (int k = 0; k < 3; ++k) eL[k] += p.xtra[(size_t)slot * XTRA_ROW + 6 + k];
+    }
 }
-
-constexpr int LPRI = 10;           // prior 9 | {row0,row1}: what the belief phase of a tile needs per landmark (LDS)
 
 GBP_DEV void wave_lds_sync()
 {
@@ -341,36 +368,68 @@ GBP_DEV void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// The landmark beliefs of a tile from the wave's LDS scratch: prior + messages in adj_factors order (gbp.py:182-193), then
-// mu = Lambda^-1 eta.  Nine lanes per landmark add one belief entry each (seven landmarks per pass; the order of the additions
-// per entry is the reference's), the sums go back through the prior slots, and one lane per landmark does the 3x3 solve and
-// writes the record.  (One lane per landmark reading 9 doubles per message was the longest phase of the loop: 27 % of the
-// wave-time with 6 of 64 lanes busy, tools/phase_profile.py.)
-GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, double *wp, int lane, int t, int l0, int nl)
+// A landmark belief from its eta | Lambda (b), written in both forms: mean | covariance for the factors, eta | Lambda for the views
+GBP_DEV void lmk_belief_store(const double (&b)[9], double *__restrict__ lr)
 {
-    for (int base = 0; base < nl; base += 7) {
-        const int g = (lane * 57) >> 9;                     // lane / 9 for lane < 64
-        const int li = base + g, k = lane - g * 9;
+    double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3], sig[6];
+    spd_solve_inverse<3>(lam, eta, mu, sig);
+    double2 *d0 = reinterpret_cast<double2 *>(lr + LR_MU);
+    d0[0] = make_double2(mu[0], mu[1]); d0[1] = make_double2(mu[2], sig[0]);
+    d0[2] = make_double2(sig[1], sig[2]); d0[3] = make_double2(sig[3], sig[4]);
+    lr[LR_COV + 5] = sig[5];                                 // (the double behind it holds the landmark's slot range)
+    double2 *d1 = reinterpret_cast<double2 *>(lr + LR_BEL);
+    d1[0] = make_double2(b[0], b[1]); d1[1] = make_double2(b[2], b[3]); d1[2] = make_double2(b[4], b[5]);
+    d1[3] = make_double2(b[6], b[7]); d1[4] = make_double2(b[8], 0.0);
+}
+
+// What the belief phase of a tile needs besides the messages, fetched ahead of it: nine lanes per landmark add one belief entry
+// each, seven landmarks per pass -- lane (g, k) = (lane / 9, lane % 9) holds prior entry k of landmark 7 b + g for pass b -- and
+// lane l < nl holds landmark l's slot range relative to the tile (two bytes).
+constexpr int LMK_PASSES = (TILE_LMKS + 6) / 7;
+struct LmkPre {
+    double pri[LMK_PASSES];
+    int rows;
+};
+GBP_DEV void lmk_prefetch(const Params &p, int lane, int t, int l0, int nl, LmkPre &q)
+{
+    const int g = (lane * 57) >> 9, k = lane - g * 9;       // lane / 9 for lane < 64
+    const double *base = p.lrec + (size_t)l0 * LREC;        // wave-uniform: one address register per access
+#pragma unroll
+    for (int b = 0; b < LMK_PASSES; ++b) {
+        const int li = b * 7 + g;
+        q.pri[b] = (g < 7 && li < nl) ? base[(unsigned)(li * LREC + LR_PRIOR + k)] : 0.0;
+    }
+    q.rows = 0;
+    if (lane < nl) {
+        const int2 r = *reinterpret_cast<const int2 *>(base + (unsigned)(lane * LREC + LR_ROWS));
+        q.rows = (r.x - t * WTILE) | ((r.y - t * WTILE) << 8);
+    }
+}
+
+// The landmark beliefs of a tile from the wave's LDS scratch wl = [64][9] new messages (eta 3 | Lambda 6 per factor lane): prior +
+// messages in adj_factors order (gbp.py:182-193), then mean and covariance.  The sums go back into rows of wl that no later pass
+// reads (landmark l's factors sit in lanes >= l), and one lane per landmark solves and writes the record.  (One lane per landmark
+// reading 9 doubles per message was the longest phase of the loop: 27 % of the wave-time with 6 of 64 lanes busy.)
+GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int l0, int nl, const LmkPre &q)
+{
+    const int g = (lane * 57) >> 9, k = lane - g * 9;
+#pragma unroll
+    for (int b = 0; b < LMK_PASSES; ++b) {
+        if (b * 7 >= nl) break;                             // wave-uniform
+        const int li = b * 7 + g;
+        const int rows = __shfl(q.rows, li, 64);
         if (g < 7 && li < nl) {
-            double *pr = wp + li * LPRI;
-            const int2 rows = *reinterpret_cast<const int2 *>(pr + 9);
-            double b = pr[k];
-            for (int r = rows.x - t * WTILE; r < rows.y - t * WTILE; ++r) b += wl[r * 9 + k];
-            pr[k] = b;
+            double acc = q.pri[b];
+            for (int r = rows & 0xff; r < (rows >> 8); ++r) acc += wl[r * 9 + k];
+            wl[li * 9 + k] = acc;
         }
     }
     wave_lds_sync();
     if (lane < nl) {
-        const double *pr = wp + lane * LPRI;
         double b[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) b[k] = pr[k];
-        double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3];
-        double2 *dst = reinterpret_cast<double2 *>(p.lrec + (size_t)(l0 + lane) * LREC);
-        dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
-        dst[2] = make_double2(b[4], b[5]); dst[3] = make_double2(b[6], b[7]);
-        spd_solve<3>(lam, eta, mu);
-        dst[4] = make_double2(b[8], mu[0]); dst[5] = make_double2(mu[1], mu[2]);
+        for (int k2 = 0; k2 < 9; ++k2) b[k2] = wl[lane * 9 + k2];
+        lmk_belief_store(b, p.lrec + (size_t)(l0 + lane) * LREC);
     }
 }
 
@@ -389,7 +448,6 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 {
     __shared__ __attribute__((aligned(16))) double wls[BLOCK / 64][WTILE * CSTAGE_ROW];  // per wave: [64][9] landmark messages, then [64][20] camera-message rows
     __shared__ int wps[BLOCK / 64][WTILE];
-    __shared__ double wprs[BLOCK / 64][TILE_LMKS * LPRI];   // per wave: prior | rows of the tile's landmarks
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int t = blockIdx.x * (BLOCK / 64) + wave;
     if (t >= p.T) return;                                   // whole wave
@@ -416,26 +474,27 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
         int st = p.state[slot];
         double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
-        double etaC[6], lamC[21], muC[6], lamL[6], muL[3];
-        load_cam_record(p.cbel + (size_t)cam * CAMREC, etaC, lamC, muC);
+        double muC[6], PC[21], muL[3];
+        load_cam_record(p.cbel + (size_t)cam * CAMREC, muC, PC);
         const double *lr = p.lrec + (size_t)lmk * LREC;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) lamL[k] = lr[LR_BEL + 3 + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
 
         double eCn[6], eLn[3], MCn[21], MLn[6];
-        const bool relin = factor_core<LOSS, XTRA>(p, x0, z, st, avar, muC, muL, etaC, lamC,
-                                                   [lr](double (&e)[3]) { e[0] = lr[LR_BEL]; e[1] = lr[LR_BEL + 1]; e[2] = lr[LR_BEL + 2]; },
-                                                   lamL, qC, qL, WC, VL, eCn, eLn, MCn, MLn,
+        const bool relin = factor_core<LOSS, XTRA>(p, x0, z, st, avar, muC, PC, muL,
+                                                   [lr](double (&c)[6]) {
+#pragma unroll
+                                                       for (int k = 0; k < 6; ++k) c[k] = lr[LR_COV + k];
+                                                   },
+                                                   [&p, slot](const double (&x)[9]) {
+#pragma unroll
+                                                       for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x[k];
+                                                   },
+                                                   qC, qL, WC, VL, eCn, eLn, MCn, MLn,
                                                    XTRA ? p.xtra + (size_t)slot * XTRA_ROW : nullptr);
         {
             const unsigned long long rb = __ballot(relin);
             if (rb != 0ull && lane == __ffsll((long long)rb) - 1) relin_add(p, __popcll(rb));
-        }
-        if (relin) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x0[k];
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) { p.msg[msg_at(slot, ROW_QC + k)] = qC[k]; p.msg[msg_at(slot, ROW_QL + k)] = qL[k]; }
@@ -461,15 +520,11 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         }
     }
     if (p.stage & STAGE_NO_BELIEFS) return;                 // compute_all_messages on its own (gbp.py:46-54): whole wave
-    // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks: priors | rows into LDS, then nine lanes per landmark
-    if (lane < nl) {
-        const double *lr = p.lrec + (size_t)(l0 + lane) * LREC;
-        double *dst = wprs[wave] + lane * LPRI;
-#pragma unroll
-        for (int k = 0; k < LPRI; ++k) dst[k] = lr[LR_PRIOR + k];
-    }
+    // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks: nine lanes per landmark
+    LmkPre pre;
+    lmk_prefetch(p, lane, t, l0, nl, pre);
     wave_lds_sync();                                        // the wave's LDS writes are done (one wave: no barrier needed)
-    tile_landmark_beliefs(p, wl, wprs[wave], lane, t, l0, nl);
+    tile_landmark_beliefs(p, wl, lane, l0, nl, pre);
     // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
     // transposed, whole rows go out, 16 bytes per lane
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
@@ -551,16 +606,11 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) rec[CAM_ETA + threadIdx.x - 64] = tot[threadIdx.x - 64];
-    if (threadIdx.x == 0) {
-        double eta[6], lam[21], mu[6];
+    if (threadIdx.x < 7) {
+        double v[27];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eta[k] = tot[k];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) lam[k] = tot[6 + k];
-        spd_solve<6>(lam, eta, mu);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
-        rec[33] = 0.0;
+        for (int k = 0; k < 27; ++k) v[k] = tot[k];
+        cam_belief_store(v, rec, threadIdx.x);
     }
 }
 
@@ -582,12 +632,7 @@ GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[3 + k] += ML[k];
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) lr[LR_BEL + k] = acc[k];
-    double eta[3] = {acc[0], acc[1], acc[2]}, lam[6] = {acc[3], acc[4], acc[5], acc[6], acc[7], acc[8]}, mu[3];
-    spd_solve<3>(lam, eta, mu);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) lr[LR_MU + k] = mu[k];
+    lmk_belief_store(acc, lr);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
@@ -731,18 +776,7 @@ GBP_DEV void cam_finish_wave(const Params &p, const double *gathered, int n_part
     double v[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) v[k] = __shfl(acc, k, 64);
-    if (lane == 0) {
-        double eta[6], lam[21], mu[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) eta[k] = v[k];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) lam[k] = v[6 + k];
-        spd_solve<6>(lam, eta, mu);
-        double *rec = p.cbel + (size_t)c * CAMREC;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rec[CAM_MU + k] = mu[k];
-        rec[33] = 0.0;
-    }
+    cam_belief_store(v, p.cbel + (size_t)c * CAMREC, lane);
 }
 
 constexpr int FINISH_BLOCK = 256;

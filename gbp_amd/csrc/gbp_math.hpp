@@ -13,36 +13,45 @@
 //   factor->variable messages            gbp/gbp.py:334-373
 //   belief = prior + sum(messages)       gbp/gbp.py:176-198
 //
-// Algebraic restructuring (same maths, fewer bytes and flops than the dense reference):
-//   * Lambda_f = s J^T J is never materialised: with J = [Jc | Jl] (2x6 | 2x3) and rho = J x0 + z - h,
-//       A = s Jc^T Jc, B = s Jc^T Jl, Cc = s Jl^T Jl, a = s Jc^T rho, c = s Jl^T rho.
-//   * message to the camera   M' = A - B S^-1 B^T  with S = Cc + (Lambda_L - M_L)  becomes
-//       M' = Jc^T (s I - s^2 Jl S^-1 Jl^T) Jc,   e* = s Jc^T (rho - Jl S^-1 g),  g = c + eta_L - e_L
-//     and symmetrically for the landmark with the 6x6 T = A + (Lambda_C - M_C).
-//   * S and T are symmetric positive definite (factor block + cavity >= prior), so the general LU
-//     inverse of the reference is replaced by an unpivoted LDL^T on packed upper storage, and only
-//     the forward substitution is needed: X^T S^-1 Y = (L^-1 X)^T D^-1 (L^-1 Y).
-//   * symmetric matrices are stored packed (upper triangle, row-major): 6x6 -> 21, 3x3 -> 6;
-//   * message precisions are stored as their 2x2 cores (M = J^T Q J): 3 doubles instead of 21 / 6 (rank2_update);
-//   * message etas are stored as their 2-vectors of coefficients (e = J^T q): 2 doubles instead of 6 / 3.  The new eta is
-//     s J^T (rho - ...) -- in the span of the Jacobian -- and damping (gbp.py:368) mixes it with the old one, which was made
-//     with the same Jacobian unless the factor relinearised in this very sweep; then the damping is 0 (gbp.py:50-54: damping
-//     returns num_undamped_iters sweeps after a relinearisation), so q' = (1-d) r + d q holds in both cases.  The one
-//     configuration where it does not (num_undamped_iters = 0: damped in the relinearising sweep itself) carries the
-//     out-of-span remainder in a dense side array (Params::xtra, general sweep only).
+// Algebraic restructuring (same maths as the dense reference, fewer bytes and flops):
+//   * Lambda_f = s J^T J is never materialised: J = [Jc | Jl] (2x6 | 2x3), rho = J x0 + z - h, s = 1 / adaptive variance.
+//   * A message never leaves the span of its factor's Jacobian and is stored that way: precision M = J^T W J with a symmetric
+//     2x2 core (3 doubles instead of 21 / 6), eta e = J^T q with a coefficient pair (2 doubles instead of 6 / 3).  The new eta
+//     is s J^T (rho - ...) -- in the span -- and damping (gbp.py:368) mixes it with the old one, which was made with the same
+//     Jacobian unless the factor relinearised in this very sweep; then the damping is 0 (gbp.py:50-54), so
+//     q' = (1-d) r + d q holds in both cases.  The one configuration where it does not (damped in the relinearising sweep
+//     itself) carries the out-of-span remainder in a dense side array (Params::xtra, general sweep only).
+//   * COVARIANCE FORM (round 4).  The reference inverts, per FACTOR and per message, the factor's own block plus the cavity
+//     of the variable it eliminates (gbp.py:340-368: a 6x6 inverse for the message to the landmark, a 3x3 for the message to
+//     the camera).  With P = Lambda^-1 of the variable's BELIEF -- one inverse per VARIABLE, made where the belief is made --
+//     and the old message in core form, the matrix to invert is a rank-2 update of the belief,
+//         T = Lambda - J^T W J + s J^T J = Lambda + J^T Q J,   Q = s I - W,
+//     and everything the message needs is 2x2 algebra on G = J P J^T (Woodbury / push-through identities):
+//         J T^-1 J^T            = G (I + Q G)^-1
+//         core of the message   = s I - s^2 J T^-1 J^T = s (I - W G) (I + Q G)^-1          (no cancellation left in it)
+//         coefficients of eta   = s (rho - J T^-1 u)   = s (I + G Q)^-1 [ rho - J mu + G (q - W rho) ],   u = eta + J^T (s rho - q)
+//     (J, W, q, P, mu of the ELIMINATED variable; the result is the message to the other one).  Nothing of the belief but
+//     its mean and covariance is read by a factor.  A factor that relinearises takes its old message out first, with the old
+//     Jacobian -- P' = P + P J^T (I - W G)^-1 W J P, mu' = mu + P J^T [ (I - W G)^-1 W (J mu - G q) - q ] (`downdate`) -- and
+//     then runs the same formulas at the new point with W = 0, q = 0.  ~480 fp64 instructions per factor instead of ~1090 for
+//     the two LDL^T eliminations of rounds 1-3, a third fewer live registers; checked sweep by sweep against the dense reference
+//     maths in tests/woodbury_proto.py (numpy) and tests/test_factor_math_host.py (this header compiled for the host).
+//   * symmetric matrices are stored packed (upper triangle, row-major): 6x6 -> 21, 3x3 -> 6.
+//   * S = Lambda of a belief is SPD: unpivoted LDL^T on packed storage (spd_solve / spd_solve_inverse).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace gbp {
 
 #define GBP_DEV __device__ __forceinline__
+#define GBP_HD __host__ __device__ __forceinline__     // the per-factor maths also compiles for the host (tests/host_math.hip: unit tests, no product path)
 
 // 1/x for the pivots and depths of this path (normal, far from over/underflow): hardware seed (v_rcp_f64, ~26 bits)
 // + two Newton steps = full double precision (<= 1 ulp) in 5 dependent instructions; the IEEE division sequence
 // (v_div_scale / v_div_fmas / v_div_fixup) is twice as long and sits on every elimination's critical path.
-GBP_DEV double rcp(double x)
+GBP_HD double rcp(double x)
 {
-#ifdef GBP_IEEE_DIV
+#if defined(GBP_IEEE_DIV) || !defined(__HIP_DEVICE_COMPILE__)
     return 1.0 / x;
 #else
     double r = __builtin_amdgcn_rcp(x);
@@ -66,7 +75,7 @@ struct Intrinsics {
 // In-place LDL^T of a packed SPD matrix: on exit the diagonal holds D, the strict upper part holds
 // U = L^T (unit upper), invd[k] = 1/D_k.
 template <int N>
-GBP_DEV void ldl_factor(double (&a)[Sym<N>::size], double (&invd)[N])
+GBP_HD void ldl_factor(double (&a)[Sym<N>::size], double (&invd)[N])
 {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -84,7 +93,7 @@ GBP_DEV void ldl_factor(double (&a)[Sym<N>::size], double (&invd)[N])
 
 // b <- L^-1 b  (unit lower L = U^T from ldl_factor)
 template <int N>
-GBP_DEV void ldl_forward(const double (&a)[Sym<N>::size], double (&b)[N])
+GBP_HD void ldl_forward(const double (&a)[Sym<N>::size], double (&b)[N])
 {
 #pragma unroll
     for (int i = 1; i < N; ++i)
@@ -94,7 +103,7 @@ GBP_DEV void ldl_forward(const double (&a)[Sym<N>::size], double (&b)[N])
 
 // b <- L^-T b
 template <int N>
-GBP_DEV void ldl_backward(const double (&a)[Sym<N>::size], double (&b)[N])
+GBP_HD void ldl_backward(const double (&a)[Sym<N>::size], double (&b)[N])
 {
 #pragma unroll
     for (int i = N - 2; i >= 0; --i)
@@ -105,7 +114,7 @@ GBP_DEV void ldl_backward(const double (&a)[Sym<N>::size], double (&b)[N])
 // mu = Lambda^-1 eta for a packed SPD Lambda (VariableNode.update_belief gbp.py:192-193, and the
 // belief means of gbp.py:74).  Lambda is consumed.
 template <int N>
-GBP_DEV void spd_solve(double (&lam)[Sym<N>::size], const double (&eta)[N], double (&mu)[N])
+GBP_HD void spd_solve(double (&lam)[Sym<N>::size], const double (&eta)[N], double (&mu)[N])
 {
     double invd[N];
     ldl_factor<N>(lam, invd);
@@ -119,10 +128,36 @@ GBP_DEV void spd_solve(double (&lam)[Sym<N>::size], const double (&eta)[N], doub
 
 // Sigma = Lambda^-1 (packed) from the LDL^T factors; used only by the covariance view.
 template <int N>
-GBP_DEV void spd_inverse(double (&lam)[Sym<N>::size], double (&sig)[Sym<N>::size])
+GBP_HD void spd_inverse(double (&lam)[Sym<N>::size], double (&sig)[Sym<N>::size])
 {
     double invd[N];
     ldl_factor<N>(lam, invd);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        double e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = (i == c) ? 1.0 : 0.0;
+        ldl_forward<N>(lam, e);
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] *= invd[i];
+        ldl_backward<N>(lam, e);
+#pragma unroll
+        for (int i = 0; i <= c; ++i) sig[Sym<N>::at(i, c)] = e[i];
+    }
+}
+
+// mu = Lambda^-1 eta AND Sigma = Lambda^-1 from one factorisation (a belief in the form the factors read it: mean | covariance)
+template <int N>
+GBP_HD void spd_solve_inverse(double (&lam)[Sym<N>::size], const double (&eta)[N], double (&mu)[N], double (&sig)[Sym<N>::size])
+{
+    double invd[N];
+    ldl_factor<N>(lam, invd);
+#pragma unroll
+    for (int i = 0; i < N; ++i) mu[i] = eta[i];
+    ldl_forward<N>(lam, mu);
+#pragma unroll
+    for (int i = 0; i < N; ++i) mu[i] *= invd[i];
+    ldl_backward<N>(lam, mu);
 #pragma unroll
     for (int c = 0; c < N; ++c) {
         double e[N];
@@ -152,13 +187,15 @@ struct Rot {
 // A double literal that is not an inline constant needs a register pair; left to itself the compiler parks every one of
 // them in VGPRs outside the persistent loop of the fused sweep (20 registers held -- and spilled -- through the whole tile).
 // Born in SGPRs at the point of use they cost two s_mov each and no vector register (a VALU op takes one scalar operand).
-GBP_DEV double sconst(double c)
+GBP_HD double sconst(double c)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(c));
+#endif
     return c;
 }
 
-GBP_DEV void sincos_theta(double x, double &sn, double &cs)
+GBP_HD void sincos_theta(double x, double &sn, double &cs)
 {
     const double n = rint(x * sconst(6.36619772367581382433e-01));           // 2/pi
     double r = fma(n, sconst(-1.5707963267948966e+00), x);
@@ -184,7 +221,7 @@ GBP_DEV void sincos_theta(double x, double &sn, double &cs)
     cs = ((q + 1) & 2) ? -cc : cc;
 }
 
-GBP_DEV Rot rodrigues(double w0, double w1, double w2)
+GBP_HD Rot rodrigues(double w0, double w1, double w2)
 {
     Rot o;
     const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
@@ -218,7 +255,7 @@ GBP_DEV Rot rodrigues(double w0, double w1, double w2)
 }
 
 // h(x) = proj(K (R(w) y + t))   reprojection.py:12-24
-GBP_DEV void project(const double (&x)[9], const Intrinsics &K, double (&h)[2])
+GBP_HD void project(const double (&x)[9], const Intrinsics &K, double (&h)[2])
 {
     const Rot R = rodrigues(x[3], x[4], x[5]);
     const double p0 = R.r[0][0] * x[6] + R.r[0][1] * x[7] + R.r[0][2] * x[8] + x[0];
@@ -230,7 +267,7 @@ GBP_DEV void project(const double (&x)[9], const Intrinsics &K, double (&h)[2])
 }
 
 // h(x) and J(x) = [J_p K | J_p K dR_wx_dw(w, y) | J_p K R]   reprojection.py:27-44
-GBP_DEV void linearise(const double (&x)[9], const Intrinsics &K, double (&Jc)[2][6], double (&Jl)[2][3],
+GBP_HD void linearise(const double (&x)[9], const Intrinsics &K, double (&Jc)[2][6], double (&Jl)[2][3],
                        double (&h)[2])
 {
     const double w0 = x[3], w1 = x[4], w2 = x[5], y0 = x[6], y1 = x[7], y2 = x[8];
@@ -266,7 +303,7 @@ GBP_DEV void linearise(const double (&x)[9], const Intrinsics &K, double (&Jc)[2
 
 // Factor.robustify_loss: adaptive noise variance from the residual AT THE LINEARISATION POINT
 // (gbp.py:309-328).  loss: 1 huber, 2 constant ("m^2" without sigma^2 is the reference's, gbp.py:324).
-GBP_DEV double robust_variance(int loss, double sigma2, double nstds, double r0, double r1, bool &flag)
+GBP_HD double robust_variance(int loss, double sigma2, double nstds, double r0, double r1, bool &flag)
 {
     const double m = sqrt(r0 * r0 + r1 * r1) / sqrt(sigma2);
     flag = m > nstds;
@@ -281,97 +318,139 @@ struct Lin {
     double s, d;                         // 1 / adaptive variance, eta damping
 };
 
-// Message to the LANDMARK: eliminate the camera block (6x6).   Factor.compute_messages, v = 1  gbp.py:340-368
-//   cavity of the camera: cetaC = eta_C - e_C, clamC = Lambda_C - M_C (belief minus this factor's OLD message)
-//   T = s Jc^T Jc + clamC,  u = s Jc^T rho + cetaC          (assembled by the caller: factor_core, gbp_kernels.hpp)
-//   M_L' = Jl^T (sI - s^2 Jc T^-1 Jc^T) Jl,  e_L' = (1-d) s Jl^T (rho - Jc T^-1 u) + d e_L
-// The forward substitutions of Jc^T and u ride along with the LDL^T elimination (augmented columns) and the
-// 2x2 quadratic forms are accumulated pivot by pivot, so nothing but the shrinking trailing block stays live.
-//   qLold / qLnew: coefficients of the message eta in the rows of Jl (e_L = Jl^T q_L), eLnew = the dense new eta
-GBP_DEV void message_to_landmark(const Lin &L, double (&u)[6], double (&clamC)[21],
-                                 const double (&qLold)[2], double (&qLnew)[2], double (&eLnew)[3], double (&MLnew)[6],
-                                 double (&Vcore)[3])
+template <int N>
+GBP_HD void rank2_update(double (&T)[Sym<N>::size], const double (&j0)[N], const double (&j1)[N], const double (&Q)[3], double sign);
+
+// ---- covariance form of Factor.compute_messages (gbp.py:334-373); derivation in the header of this file ----
+// The Jacobian block of a variable is given by its two rows j0, j1.  For the camera block two entries are structurally zero
+// (d u / d t_y = d v / d t_x = 0, reprojection.py:36-38): skipped at compile time.
+template <int N>
+constexpr __host__ __device__ bool jzero(int row, int i) { return N == 6 && ((row == 0 && i == 1) || (row == 1 && i == 0)); }
+
+// pj0 = P j0, pj1 = P j1 (P packed symmetric), G = J P J^T as {G00, G01, G11}
+template <int N>
+GBP_HD void gram(const double (&P)[Sym<N>::size], const double (&j0)[N], const double (&j1)[N], double (&G)[3], double (&pj0)[N], double (&pj1)[N])
 {
-    const double s = L.s;
-    double y0[6], y1[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { y0[i] = L.Jc[0][i]; y1[i] = L.Jc[1][i]; }
-    double H00 = 0.0, H01 = 0.0, H11 = 0.0, k0 = 0.0, k1 = 0.0;
+    for (int i = 0; i < N; ++i) {
+        double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double r = rcp(clamC[Sym<6>::at(k, k)]);
-        const double t0 = y0[k] * r, t1 = y1[k] * r;
-        H00 += t0 * y0[k]; H01 += t0 * y1[k]; H11 += t1 * y1[k];
-        k0 += t0 * u[k]; k1 += t1 * u[k];
-#pragma unroll
-        for (int i = k + 1; i < 6; ++i) {
-            const double m = clamC[Sym<6>::at(k, i)] * r;
-#pragma unroll
-            for (int j = i; j < 6; ++j) clamC[Sym<6>::at(i, j)] -= m * clamC[Sym<6>::at(k, j)];
-            y0[i] -= m * y0[k]; y1[i] -= m * y1[k]; u[i] -= m * u[k];
+        for (int j = 0; j < N; ++j) {
+            const double pij = P[i <= j ? Sym<N>::at(i, j) : Sym<N>::at(j, i)];
+            if (!jzero<N>(0, j)) a += pij * j0[j];
+            if (!jzero<N>(1, j)) b += pij * j1[j];
         }
+        pj0[i] = a; pj1[i] = b;
     }
-    const double V00 = s - s * s * H00, V01 = -(s * s) * H01, V11 = s - s * s * H11;
-    Vcore[0] = V00; Vcore[1] = V01; Vcore[2] = V11;
-    const double r0 = s * (L.rho[0] - k0), r1 = s * (L.rho[1] - k1);
-    double VJ0[3], VJ1[3];
+    double g00 = 0.0, g01 = 0.0, g11 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        VJ0[j] = V00 * L.Jl[0][j] + V01 * L.Jl[1][j];
-        VJ1[j] = V01 * L.Jl[0][j] + V11 * L.Jl[1][j];
+    for (int i = 0; i < N; ++i) {
+        if (!jzero<N>(0, i)) { g00 += j0[i] * pj0[i]; g01 += j0[i] * pj1[i]; }
+        if (!jzero<N>(1, i)) g11 += j1[i] * pj1[i];
     }
-    qLnew[0] = (1.0 - L.d) * r0 + L.d * qLold[0];
-    qLnew[1] = (1.0 - L.d) * r1 + L.d * qLold[1];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        eLnew[i] = L.Jl[0][i] * qLnew[0] + L.Jl[1][i] * qLnew[1];
-#pragma unroll
-        for (int j = i; j < 3; ++j) MLnew[Sym<3>::at(i, j)] = L.Jl[0][i] * VJ0[j] + L.Jl[1][i] * VJ1[j];
-    }
+    G[0] = g00; G[1] = g01; G[2] = g11;
 }
 
-// Message to the CAMERA: eliminate the landmark block (3x3).   Factor.compute_messages, v = 0  gbp.py:340-368
-//   cavity of the landmark: cetaL = eta_L - e_L, clamL = Lambda_L - M_L (OLD landmark message)
-//   S = s Jl^T Jl + clamL,  g = s Jl^T rho + cetaL          (assembled by the caller)
-//   M_C' = Jc^T (sI - s^2 Jl S^-1 Jl^T) Jc,  e_C' = (1-d) s Jc^T (rho - Jl S^-1 g) + d e_C = Jc^T q_C'   (qC in: old, out: new)
-GBP_DEV void message_to_camera(const Lin &L, double (&g)[3], double (&clamL)[6],
-                               double (&qC)[2], double (&eCnew)[6], double (&MCnew)[21], double (&Wcore)[3])
+// G = J P J^T alone: a row of P J^T is used as soon as it is made (nothing but the three sums stays live)
+template <int N>
+GBP_HD void gram_only(const double (&P)[Sym<N>::size], const double (&j0)[N], const double (&j1)[N], double (&G)[3])
 {
-    const double s = L.s;
-    double y0[3], y1[3];
+    double g00 = 0.0, g01 = 0.0, g11 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { y0[i] = L.Jl[0][i]; y1[i] = L.Jl[1][i]; }
-    double G00 = 0.0, G01 = 0.0, G11 = 0.0, k0 = 0.0, k1 = 0.0;
+    for (int i = 0; i < N; ++i) {
+        double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double r = rcp(clamL[Sym<3>::at(k, k)]);
-        const double t0 = y0[k] * r, t1 = y1[k] * r;
-        G00 += t0 * y0[k]; G01 += t0 * y1[k]; G11 += t1 * y1[k];
-        k0 += t0 * g[k]; k1 += t1 * g[k];
-#pragma unroll
-        for (int i = k + 1; i < 3; ++i) {
-            const double m = clamL[Sym<3>::at(k, i)] * r;
-#pragma unroll
-            for (int j = i; j < 3; ++j) clamL[Sym<3>::at(i, j)] -= m * clamL[Sym<3>::at(k, j)];
-            y0[i] -= m * y0[k]; y1[i] -= m * y1[k]; g[i] -= m * g[k];
+        for (int j = 0; j < N; ++j) {
+            const double pij = P[i <= j ? Sym<N>::at(i, j) : Sym<N>::at(j, i)];
+            if (!jzero<N>(0, j)) a += pij * j0[j];
+            if (!jzero<N>(1, j)) b += pij * j1[j];
         }
+        if (!jzero<N>(0, i)) { g00 += j0[i] * a; g01 += j0[i] * b; }
+        if (!jzero<N>(1, i)) g11 += j1[i] * b;
     }
-    const double W00 = s - s * s * G00, W01 = -(s * s) * G01, W11 = s - s * s * G11;
-    Wcore[0] = W00; Wcore[1] = W01; Wcore[2] = W11;
-    const double r0 = s * (L.rho[0] - k0), r1 = s * (L.rho[1] - k1);
-    double WJ0[6], WJ1[6];
+    G[0] = g00; G[1] = g01; G[2] = g11;
+}
+
+template <int N>
+GBP_HD void jdot(const double (&j0)[N], const double (&j1)[N], const double (&x)[N], double (&m)[2])
+{
+    double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        WJ0[j] = W00 * L.Jc[0][j] + W01 * L.Jc[1][j];
-        WJ1[j] = W01 * L.Jc[0][j] + W11 * L.Jc[1][j];
+    for (int i = 0; i < N; ++i) {
+        if (!jzero<N>(0, i)) a += j0[i] * x[i];
+        if (!jzero<N>(1, i)) b += j1[i] * x[i];
     }
-    qC[0] = (1.0 - L.d) * r0 + L.d * qC[0];
-    qC[1] = (1.0 - L.d) * r1 + L.d * qC[1];
+    m[0] = a; m[1] = b;
+}
+
+// The message that eliminating a variable leaves for the other one:
+//   (P, mu) covariance and mean of the eliminated variable's belief, (W, q) core and eta coefficients of this factor's OLD
+//   message to it (made with the SAME Jacobian rows j0, j1), rho = J x0 + z - h, s = 1 / variance.
+//   core = s (I - W G)(I + Q G)^-1 (symmetric),  r = s (I + G Q)^-1 [rho - J mu + G (q - W rho)],  Q = s I - W.
+template <int N>
+GBP_HD void eliminate(const double (&P)[Sym<N>::size], const double (&mu)[N], const double (&j0)[N], const double (&j1)[N],
+                      const double (&W)[3], const double (&q)[2], const double (&rho)[2], double s, double (&core)[3], double (&r)[2])
+{
+    double G[3], m[2];
+    gram_only<N>(P, j0, j1, G);
+    jdot<N>(j0, j1, mu, m);
+    // E = I - W G,  D = I + Q G = E + s G   (general 2x2)
+    const double e00 = 1.0 - (W[0] * G[0] + W[1] * G[1]), e01 = -(W[0] * G[1] + W[1] * G[2]);
+    const double e10 = -(W[1] * G[0] + W[2] * G[1]), e11 = 1.0 - (W[1] * G[1] + W[2] * G[2]);
+    const double d00 = e00 + s * G[0], d01 = e01 + s * G[1], d10 = e10 + s * G[1], d11 = e11 + s * G[2];
+    const double idet = rcp(d00 * d11 - d01 * d10);
+    const double i00 = d11 * idet, i01 = -d01 * idet, i10 = -d10 * idet, i11 = d00 * idet;      // D^-1
+    core[0] = s * (e00 * i00 + e01 * i10);
+    core[1] = 0.5 * s * ((e00 * i01 + e01 * i11) + (e10 * i00 + e11 * i10));
+    core[2] = s * (e10 * i01 + e11 * i11);
+    const double t0 = q[0] - (W[0] * rho[0] + W[1] * rho[1]), t1 = q[1] - (W[1] * rho[0] + W[2] * rho[1]);
+    const double b0 = (rho[0] - m[0]) + (G[0] * t0 + G[1] * t1), b1 = (rho[1] - m[1]) + (G[1] * t0 + G[2] * t1);
+    r[0] = s * (i00 * b0 + i10 * b1);                       // (I + G Q)^-1 = (D^-1)^T
+    r[1] = s * (i01 * b0 + i11 * b1);
+}
+
+// belief minus this factor's old message, in covariance form:  P <- (Lambda - J^T W J)^-1,  mu <- P (eta - J^T q)
+template <int N>
+GBP_HD void downdate(double (&P)[Sym<N>::size], double (&mu)[N], const double (&j0)[N], const double (&j1)[N], const double (&W)[3], const double (&q)[2])
+{
+    double G[3], pj0[N], pj1[N], m[2];
+    gram<N>(P, j0, j1, G, pj0, pj1);
+    jdot<N>(j0, j1, mu, m);
+    const double e00 = 1.0 - (W[0] * G[0] + W[1] * G[1]), e01 = -(W[0] * G[1] + W[1] * G[2]);
+    const double e10 = -(W[1] * G[0] + W[2] * G[1]), e11 = 1.0 - (W[1] * G[1] + W[2] * G[2]);
+    const double idet = rcp(e00 * e11 - e01 * e10);
+    const double i00 = e11 * idet, i01 = -e01 * idet, i10 = -e10 * idet, i11 = e00 * idet;      // (I - W G)^-1
+    double A[3];                                            // A = (I - W G)^-1 W, symmetric
+    A[0] = i00 * W[0] + i01 * W[1];
+    A[1] = 0.5 * ((i00 * W[1] + i01 * W[2]) + (i10 * W[0] + i11 * W[1]));
+    A[2] = i10 * W[1] + i11 * W[2];
+    const double v0 = m[0] - (G[0] * q[0] + G[1] * q[1]), v1 = m[1] - (G[1] * q[0] + G[2] * q[1]);
+    const double t0 = A[0] * v0 + A[1] * v1 - q[0], t1 = A[1] * v0 + A[2] * v1 - q[1];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        eCnew[i] = L.Jc[0][i] * qC[0] + L.Jc[1][i] * qC[1];
+    for (int i = 0; i < N; ++i) mu[i] += pj0[i] * t0 + pj1[i] * t1;
+    rank2_update<N>(P, pj0, pj1, A, 1.0);
+}
+
+// c0 * j0[i] + c1 * j1[i] without the structurally zero term (i is a compile-time constant after unrolling)
+template <int N>
+GBP_HD double jcomb(int i, double c0, double c1, const double (&j0)[N], const double (&j1)[N])
+{
+    if (jzero<N>(0, i)) return c1 * j1[i];
+    if (jzero<N>(1, i)) return c0 * j0[i];
+    return c0 * j0[i] + c1 * j1[i];
+}
+
+// dense form of a message for the belief sums: e = J^T q, M = J^T Q J (packed)
+template <int N>
+GBP_HD void dense_message(const double (&j0)[N], const double (&j1)[N], const double (&q)[2], const double (&Q)[3], double (&e)[N],
+                          double (&M)[Sym<N>::size])
+{
 #pragma unroll
-        for (int j = i; j < 6; ++j) MCnew[Sym<6>::at(i, j)] = L.Jc[0][i] * WJ0[j] + L.Jc[1][i] * WJ1[j];
+    for (int j = 0; j < N; ++j) {
+        const double a = jcomb<N>(j, Q[0], Q[1], j0, j1), b = jcomb<N>(j, Q[1], Q[2], j0, j1);
+        e[j] = jcomb<N>(j, q[0], q[1], j0, j1);
+#pragma unroll
+        for (int i = 0; i <= j; ++i) M[Sym<N>::at(i, j)] = jcomb<N>(i, a, b, j0, j1);
     }
 }
 
@@ -380,7 +459,7 @@ GBP_DEV void message_to_camera(const Lin &L, double (&g)[3], double (&clamL)[6],
 // message instead of the packed 21 / 6; the dense matrix is rebuilt from the Jacobian at the linearisation point the
 // message was computed with.   T += sign * J^T Q J   on packed upper storage, J given by its two rows.
 template <int N>
-GBP_DEV void rank2_update(double (&T)[Sym<N>::size], const double (&j0)[N], const double (&j1)[N], const double (&Q)[3],
+GBP_HD void rank2_update(double (&T)[Sym<N>::size], const double (&j0)[N], const double (&j1)[N], const double (&Q)[3],
                           double sign)
 {
 #pragma unroll
@@ -393,7 +472,7 @@ GBP_DEV void rank2_update(double (&T)[Sym<N>::size], const double (&j0)[N], cons
 }
 
 // max over all 81 signed entries of Lambda_f = s J^T J (np.max(factor.factor.lam), gbp_ba.py:31)
-GBP_DEV double factor_lambda_max(const double (&Jc)[2][6], const double (&Jl)[2][3], double s)
+GBP_HD double factor_lambda_max(const double (&Jc)[2][6], const double (&Jl)[2][3], double s)
 {
     double J0[9], J1[9];
 #pragma unroll

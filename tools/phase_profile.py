@@ -7,12 +7,13 @@ wave-time (mean over the 2048 waves of the last sweep).  Run on the GPU box.
 """
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); REPO = os.path.dirname(HERE)
-LIB = os.path.join(HERE, 'libgbp_phase.so')
+LIB = os.environ.get('PHASE_LIB', os.path.join(HERE, 'libgbp_phase.so'))
+EXTRA = os.environ.get('PHASE_DEFS', '').split()
 NAMES = ['ticket+descriptor', 'issue stream loads', 'lmk beliefs of prev tile (LDS)', 'wait streams', 'camera gather', 'lmk records via LDS',
          'maths', 'stores issued', 'wait accumulation turn', 'accumulate + loop', 'wait for the other waves at the end', 'table write-out']
 if not os.path.exists(LIB) or '--build-only' in sys.argv:
     csrc = os.path.join(REPO, 'gbp_amd', 'csrc')
-    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DGBP_PHASE_TIMING',
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DGBP_PHASE_TIMING'] + EXTRA + [
                            '-o', LIB, 'gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip'], cwd=csrc)
     if '--build-only' in sys.argv:
         sys.exit(0)
@@ -36,7 +37,8 @@ share = out.astype(np.float64).sum(axis=0) / tot.sum()
 for n, s, m in zip(NAMES, share, out.astype(np.float64).mean(axis=0)):
     print(f"  {n:34s} {100 * s:5.1f} %   {m:9.0f} ticks/wave")
 # per-workgroup finishing time (its slowest wave): the kernel lasts as long as the slowest workgroup
-wg = tot.reshape(-1, 8).max(axis=1)
+nb = ct.c_int32(); _capi.check(e._lib.gbp_ba_info(e._h, None, None, ct.byref(nb)))
+wg = tot.reshape(nb.value, -1).max(axis=1)
 print(f"workgroups {wg.size}: finishing ticks mean {wg.mean():.0f} min {wg.min():.0f} max {wg.max():.0f}  (max / mean = {wg.max() / wg.mean():.3f})")
 for x in range(8):
     s = wg[x::8]
