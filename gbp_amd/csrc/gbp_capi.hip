@@ -641,7 +641,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
         const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
-                          + (size_t)std::max(C, 1) * (CAMREC + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
+                          + (size_t)std::max(C, 1) * (CAMREC + CBEL + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
                           + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);
         CHK(arena_reserve(h, need));
@@ -652,6 +652,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
     CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
     CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
+    CHK(dev_alloc(h, &p.cbelief, (size_t)std::max(C, 1) * CBEL));
     p.meta = d_meta; p.tiles = d_tiles; p.cptr = cptr; p.cadj = cadj; p.cpos = cpos;
     if (T) {
         BuildArgs a{d_tiles, d_lrow0, lptr, lm2ref, h->d_ref_cam, ref_file, cam_means, lmk_means, meas, d_meta, cadj, cpos};
@@ -1259,8 +1260,8 @@ int gbp_ba_energy(gbp_ba_t *h, double *out)
 static void unpack6(const double *pk, double *dense) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) dense[i * 6 + j] = pk[Sym<6>::at(std::min(i, j), std::max(i, j))]; }
 static void unpack3(const double *pk, double *dense) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dense[i * 3 + j] = pk[Sym<3>::at(std::min(i, j), std::max(i, j))]; }
 
-// cameras: records of `cam_stride` doubles with (eta 6 | Lambda 21) at cam_off; landmarks: lrec with (eta 3 | Lambda 6) at lmk_off
-static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_off, int lmk_off,
+// cameras: rows of `cam_stride` doubles with (eta 6 | Lambda 21) in front; landmarks: rows of `lmk_stride` doubles with (eta 3 | Lambda 6) at lmk_off
+static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, const double *d_lmk, int lmk_stride, int lmk_off,
                         double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     const Params &p = h->p;
@@ -1268,16 +1269,16 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_
         std::vector<double> cb;
         CHK(download(h, cb, d_cam, (size_t)std::max(p.C, 1) * cam_stride));
         for (int c = 0; c < p.C; ++c) {
-            if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)c * 6 + k] = cb[(size_t)c * cam_stride + cam_off + k];
-            if (cam_lam) unpack6(&cb[(size_t)c * cam_stride + cam_off + 6], cam_lam + (size_t)c * 36);
+            if (cam_eta) for (int k = 0; k < 6; ++k) cam_eta[(size_t)c * 6 + k] = cb[(size_t)c * cam_stride + k];
+            if (cam_lam) unpack6(&cb[(size_t)c * cam_stride + 6], cam_lam + (size_t)c * 36);
         }
     }
     if (lmk_eta || lmk_lam) {
         std::vector<double> lr;
-        CHK(download(h, lr, p.lrec, (size_t)std::max(p.L, 1) * LREC));
+        CHK(download(h, lr, d_lmk, (size_t)std::max(p.L, 1) * lmk_stride));
         for (int l = 0; l < p.L; ++l) {
-            if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)l * 3 + k] = lr[(size_t)l * LREC + lmk_off + k];
-            if (lmk_lam) unpack3(&lr[(size_t)l * LREC + lmk_off + 3], lmk_lam + (size_t)l * 9);
+            if (lmk_eta) for (int k = 0; k < 3; ++k) lmk_eta[(size_t)l * 3 + k] = lr[(size_t)l * lmk_stride + lmk_off + k];
+            if (lmk_lam) unpack3(&lr[(size_t)l * lmk_stride + lmk_off + 3], lmk_lam + (size_t)l * 9);
         }
     }
     return GBP_OK;
@@ -1286,13 +1287,24 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, int cam_
 int gbp_ba_get_beliefs(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
-    return get_var_info(h, h->p.cbel, CAMREC, CAM_ETA, LR_BEL, cam_eta, cam_lam, lmk_eta, lmk_lam);
+    const Params &p = h->p;
+    const double *d_lmk = nullptr;
+    if (lmk_eta || lmk_lam) {
+        // VariableNode.belief of the landmarks is a view formed from mean | covariance (k_lmk_belief_view); zeros before the first
+        // update_all_beliefs, like the reference's freshly constructed nodes (gbp.py:164)
+        CHK(ensure_tmp(h, sizeof(double) * 9 * (size_t)std::max(p.L, 1)));
+        if (!h->has_beliefs) HIPCHK(hipMemsetAsync(h->d_tmp, 0, sizeof(double) * 9 * (size_t)std::max(p.L, 1), h->stream));
+        else if (p.L) hipLaunchKernelGGL(k_lmk_belief_view, dim3(grid_for((size_t)p.L)), dim3(BLOCK), 0, h->stream, p, h->d_tmp);
+        HIPCHK(hipGetLastError());
+        d_lmk = h->d_tmp;
+    }
+    return get_var_info(h, p.cbelief, CBEL, d_lmk, 9, 0, cam_eta, cam_lam, lmk_eta, lmk_lam);
 }
 
 int gbp_ba_get_priors(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
-    return get_var_info(h, h->p.cprior, 27, 0, LR_PRIOR, cam_eta, cam_lam, lmk_eta, lmk_lam);
+    return get_var_info(h, h->p.cprior, 27, h->p.lrec, LREC, LR_PRIOR, cam_eta, cam_lam, lmk_eta, lmk_lam);
 }
 
 int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
@@ -1600,7 +1612,7 @@ std::vector<StatePart> state_parts(gbp_ba *h)
     const Params &p = h->p;
     const size_t S = (size_t)p.T * WTILE;
     return {{p.lin, S * LIN_ROWS * sizeof(double)}, {p.msg, S * MSG_ROWS * sizeof(double)}, {p.state, S * sizeof(int)},
-            {p.lrec, (size_t)p.L * LREC * sizeof(double)}, {p.cbel, (size_t)p.C * CAMREC * sizeof(double)},
+            {p.lrec, (size_t)p.L * LREC * sizeof(double)}, {p.cbel, (size_t)p.C * CAMREC * sizeof(double)}, {p.cbelief, (size_t)p.C * CBEL * sizeof(double)},
             {p.cprior, (size_t)p.C * 27 * sizeof(double)}, {p.xtra, p.xtra ? S * XTRA_ROW * sizeof(double) : 0}};
 }
 }  // namespace

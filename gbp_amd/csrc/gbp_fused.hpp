@@ -132,7 +132,7 @@ GBP_DEV void st2(double *__restrict__ base, unsigned byte_off, double x, double 
 GBP_DEV void st1(double *__restrict__ base, unsigned byte_off, double x) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off) = x; }
 
 template <int LOSS, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles, const int *__restrict__ blk_begin)
+__global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *acc = smem;                                              // [C][27]
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
-    const int tb = blk_begin[blockIdx.x], ntl = blk_begin[blockIdx.x + 1] - tb;
+    // the workgroup's contiguous range of tiles, computed (a table of range starts cost a dependent load before the first tile)
+    const int tb = (int)((long long)blockIdx.x * p.T / gridDim.x), ntl = (int)((long long)(blockIdx.x + 1) * p.T / gridDim.x) - tb;
 
     // The landmark beliefs of a tile (LDS work, no loads) are formed one iteration LATE, after the next tile's loads have
     // been issued, so that the wave has HBM requests in flight meanwhile.  The tile's landmark messages wait in the wave's LDS
@@ -173,26 +174,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         ti = __builtin_amdgcn_readfirstlane(ti);
         const bool valid = ti < ntl;
         const int t = tb + (valid ? (a.reverse ? ntl - 1 - ti : ti) : 0);
-        int4 td = make_int4(0, 0, 0, 0);
-        if (valid) td = tiles[t];
+#ifdef GBP_DESC_FIRST                                      // A/B: the descriptor's round trip in front of the streams (rounds 1-3)
+        const int4 td = tiles[valid ? t : tb];
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
-        GBP_PH(0);                                         // ticket + descriptor
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        GBP_PH(0);                                         // ticket
         if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
             if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
             GBP_PH_NOWAIT(2);
             break;
-        }
-
-        // the heads (mean | covariance | rows) of the tile's landmark records: ten doubles of every thirty, fetched by the whole wave
-        const int nhead2 = max(nl, 1) * (LHEAD / 2);       // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
-        const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
-        constexpr int NSTAGE = (TILE_LMKS * (LHEAD / 2) + 63) / 64;
-        double2 stage[NSTAGE];
-#pragma unroll
-        for (int j = 0; j < NSTAGE; ++j) {
-            const int i = j * 64 + lane, rec = (i * 205) >> 10, piece = i - rec * (LHEAD / 2);    // i / 5, exact for i < 128
-            stage[j] = i < nhead2 ? lsrc[rec * (LREC / 2) + piece] : make_double2(0.0, 0.0);
         }
 
         // everything the factor streams: six + five row pairs of the tile's block, 16 bytes per lane each
@@ -215,6 +207,24 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             qC[0] = m0.x; qC[1] = m0.y; qL[0] = m1.x; qL[1] = m1.y;
             WC[0] = m2.x; WC[1] = m2.y; WC[2] = m3.x; VL[0] = m3.y; VL[1] = m4.x; VL[2] = m4.y;
         }
+        // the tile's descriptor, and the heads (mean | covariance | rows) of its landmark records: ten doubles of every twenty,
+        // fetched by the whole wave.  (Behind the streams, which need nothing but the tile index: the descriptor's round trip
+        // overlaps theirs instead of preceding it.)
+#ifndef GBP_DESC_FIRST
+        const int4 td = tiles[t];
+        const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
+        const bool active = lane < nf;
+#endif
+        const int nhead2 = max(nl, 1) * (LHEAD / 2);       // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
+        const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
+        constexpr int NSTAGE = (TILE_LMKS * (LHEAD / 2) + 63) / 64;
+        double2 stage[NSTAGE];
+#pragma unroll
+        for (int j = 0; j < NSTAGE; ++j) {
+            const int i = j * 64 + lane, rec = (i * 205) >> 10, piece = i - rec * (LHEAD / 2);    // i / 5, exact for i < 128
+            stage[j] = i < nhead2 ? lsrc[rec * (LREC / 2) + piece] : make_double2(0.0, 0.0);            // (heads: every other 80 bytes)
+        }
+
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
@@ -321,8 +331,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
 // of travelling through a camera-major staging buffer (27 doubles written + read, scattered: the general sweep).  Same tile
 // walk, same in-order accumulation by (workgroup, tile, rank): the sums are bitwise those a single table would give.
 template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a, const int4 *__restrict__ tiles,
-                                                                        const int *__restrict__ blk_begin)
+__global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *acc = smem;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a,
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
-    const int tb = blk_begin[blockIdx.x], ntl = blk_begin[blockIdx.x + 1] - tb;
+    const int tb = (int)((long long)blockIdx.x * p.T / gridDim.x), ntl = (int)((long long)(blockIdx.x + 1) * p.T / gridDim.x) - tb;
     for (;;) {
         int ti = 0;
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
@@ -385,49 +394,61 @@ __global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a,
 }
 
 // One workgroup per camera: partial[c] = sum over the per-workgroup tables in a fixed order (bitwise reproducible).
-// The camera's n_blocks x 27 run is copied to LDS with fully coalesced 16-byte loads (a lane-per-table read touches 64
-// different lines per instruction and was TA-bound: 12.4 us); then 9 x 27 threads add every 9th table and 27 threads add
-// the nine partial sums.  With finish != 0 (single GPU: nothing to exchange) the camera belief is completed in place:
-// prior + sum, 6x6 solve (VariableNode.update_belief gbp.py:182-193), which saves a dependent launch.
-constexpr int RED_PARTS = 9;
-constexpr int RED_THREADS = 1024;      // the copy into LDS is the latency of this kernel: 1024 threads put the camera's whole run
-                                       // (55 KB at 256 workgroups) in flight at once, four 16-byte loads per thread (256 threads with a
-                                       // rolled loop: 8.1 us at C = 500 and 9.0 us for the 63 cameras of fr1desk)
-__global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
-                                                                 double *__restrict__ partial, int finish, PeerOut peer, unsigned long long *clk)
+// The camera's n_blocks x 28 run is contiguous (55 KB at 256 workgroups).  Thread (part, pair) = (tid / 14, tid % 14) adds the 16-byte
+// piece `pair` of rows part, part + 73, ... straight from memory -- every load instruction of the block reads one contiguous 16 KB
+// chunk, four per thread in flight -- then 9 x 28 threads add every 9th partial sum and 27 threads the last nine.  (Rounds 1-3
+// copied the run to LDS first and let 9 x 27 threads walk it: 8.3 us per launch, most of it the copy's round trip and a 28-step
+// dependent chain per thread.)  With finish != 0 (single GPU: nothing to exchange) the camera belief is completed in place:
+// prior + sum, mean and covariance by seven lanes (VariableNode.update_belief gbp.py:182-193), which saves a dependent launch.
+constexpr int RED_THREADS = 1024;
+constexpr int RED_PAIRS = TROW / 2;                 // 16-byte pieces per row
+constexpr int RED_PARTS = RED_THREADS / RED_PAIRS;  // 73 partial sums per entry ...
+constexpr int RED_G = 9;                            // ... then 9, then 1
+constexpr int RED_LDS_DOUBLES = (RED_PARTS + RED_G) * TROW + 28;
+
+// returns entry tid (< 27) of the camera's sum in threads 0..26 (0.0 elsewhere); red = RED_LDS_DOUBLES doubles of LDS.  The caller
+// synchronises the block before red is used again.
+GBP_DEV double cam_reduce_sum(const double *__restrict__ src, int n_blocks, double *red, int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][27] | red[RED_PARTS][27] | tot[27]
-    const int c = blockIdx.x, n = n_blocks * TROW, tid = threadIdx.x;
-    clk_begin(clk);
-    double *red = sh + ((n + 1) & ~1), *tot = red + RED_PARTS * 27;
-    const double *src = block_partials + (size_t)c * n;
-    if (((size_t)c * n & 1) == 0) {
+    double *red2 = red + RED_PARTS * TROW;
+    const int part = tid / RED_PAIRS, pair = tid - part * RED_PAIRS;
+    if (part < RED_PARTS) {
         const double2 *s2 = reinterpret_cast<const double2 *>(src);
-        const int n2 = n / 2;
-        for (int i0 = tid; i0 < n2; i0 += 4 * RED_THREADS) {
+        double sx = 0.0, sy = 0.0;
+        for (int b0 = part; b0 < n_blocks; b0 += 4 * RED_PARTS) {
             double2 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int i = i0 + j * RED_THREADS; v[j] = i < n2 ? s2[i] : make_double2(0.0, 0.0); }
+            for (int j = 0; j < 4; ++j) { const int bb = b0 + j * RED_PARTS; v[j] = bb < n_blocks ? s2[(size_t)bb * RED_PAIRS + pair] : make_double2(0.0, 0.0); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int i = i0 + j * RED_THREADS; if (i < n2) { sh[2 * i] = v[j].x; sh[2 * i + 1] = v[j].y; } }
+            for (int j = 0; j < 4; ++j) { sx += v[j].x; sy += v[j].y; }
         }
-        if ((n & 1) && tid == 0) sh[n - 1] = src[n - 1];
-    } else {
-        for (int i = tid; i < n; i += RED_THREADS) sh[i] = src[i];
+        reinterpret_cast<double2 *>(red)[part * RED_PAIRS + pair] = make_double2(sx, sy);
     }
     __syncthreads();
-    if (tid < RED_PARTS * 27) {
-        const int part = tid / 27, k = tid - part * 27;
+    if (tid < RED_G * TROW) {
+        const int g = tid / TROW, k = tid - g * TROW;
         double s = 0.0;
-        for (int b = part; b < n_blocks; b += RED_PARTS) s += sh[b * TROW + k];
-        red[part * 27 + k] = s;
+        for (int q = g; q < RED_PARTS; q += RED_G) s += red[q * TROW + k];
+        red2[g * TROW + k] = s;
     }
     __syncthreads();
     double s = 0.0;
     if (tid < 27) {
-        s = red[tid];
 #pragma unroll
-        for (int q = 1; q < RED_PARTS; ++q) s += red[q * 27 + tid];
+        for (int g = 0; g < RED_G; ++g) s += red2[g * TROW + tid];
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
+                                                                 double *__restrict__ partial, int finish, PeerOut peer, unsigned long long *clk)
+{
+    __shared__ __attribute__((aligned(16))) double sh[RED_LDS_DOUBLES];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    clk_begin(clk);
+    double *tot = sh + (RED_PARTS + RED_G) * TROW;
+    const double s = cam_reduce_sum(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);
+    if (tid < 27) {
         partial[(size_t)c * 27 + tid] = s;
         tot[tid] = s + p.cprior[(size_t)c * 27 + tid];
     }
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     if (!finish) return;
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
-    if (tid >= 64 && tid < 64 + 27) rec[CAM_ETA + tid - 64] = tot[tid - 64];      // eta | Lambda: one store instruction of another wave
+    if (tid >= 64 && tid < 64 + 27) p.cbelief[(size_t)c * CBEL + tid - 64] = tot[tid - 64];      // eta | Lambda: one store instruction of another wave
     if (tid < 7) {                                          // mean and the six columns of the covariance, one lane each
         double v[27];
 #pragma unroll
@@ -446,46 +467,23 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
 
 // Sharded sweep with the peer-store exchange, everything after the sweep kernel in ONE launch: a small grid of persistent
 // workgroups first reduces and PUSHES all of its cameras (workgroup tables -> 27 sums -> row c of every rank's mailbox + tag),
-// then finishes them, one wave per camera: wait for the n_ranks tags of row c, add the parts in rank order, prior, 6x6 solve.
+// then finishes them, one wave per camera: wait for the n_ranks tags of row c, add the parts in rank order, prior, mean | covariance.
 // Every workgroup of every rank pushes before it waits, and the grid is never larger than what is resident at once (XCHG_BLOCKS = two
 // 1024-thread workgroups per CU of an MI355X; one camera per workgroup up to 512 cameras, several beyond), so ranks cannot wait for
-// each other in a cycle (__launch_bounds__(1024, 8): 64 VGPRs, the 6x6 solve of the finish spills ~40 of them -- one lane, once per
-// camera -- so that TWO workgroups fit a CU; fused_launch caps the grid at what the occupancy query admits).  Against reduce -> finish as two launches
-// this saves a kernel boundary and the global "all rows are out" hand-off; against RCCL also the collective's launch and sync.
+// each other in a cycle (__launch_bounds__(1024, 8): 64 VGPRs so that TWO workgroups fit a CU; fused_launch caps the grid at what the
+// occupancy query admits).  Against reduce -> finish as two launches this saves a kernel boundary and the global "all rows are out"
+// hand-off; against RCCL also the collective's launch and sync.
 constexpr int XCHG_BLOCKS = 512;
 __global__ __launch_bounds__(RED_THREADS, 8) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
                                                                  double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];      // [n_blocks][28] | red[RED_PARTS][27]
-    const int n = n_blocks * TROW, tid = threadIdx.x;
-    double *red = sh + ((n + 1) & ~1);
+    __shared__ __attribute__((aligned(16))) double sh[RED_LDS_DOUBLES];
+    const int tid = threadIdx.x;
     clk_begin(clk);
     for (int c = blockIdx.x; c < p.C; c += gridDim.x) {
-        const double2 *s2 = reinterpret_cast<const double2 *>(block_partials + (size_t)c * n);      // (TROW is even: 16-byte aligned)
-        const int n2 = n / 2;
-        for (int i0 = tid; i0 < n2; i0 += 4 * RED_THREADS) {
-            double2 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int i = i0 + j * RED_THREADS; v[j] = i < n2 ? s2[i] : make_double2(0.0, 0.0); }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int i = i0 + j * RED_THREADS; if (i < n2) { sh[2 * i] = v[j].x; sh[2 * i + 1] = v[j].y; } }
-        }
-        __syncthreads();
-        if (tid < RED_PARTS * 27) {
-            const int part = tid / 27, k = tid - part * 27;
-            double s = 0.0;
-            for (int b = part; b < n_blocks; b += RED_PARTS) s += sh[b * TROW + k];
-            red[part * 27 + k] = s;
-        }
-        __syncthreads();
+        const double s = cam_reduce_sum(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);      // the same order as k_cam_reduce_tree: bitwise the same sums
         if (tid < 64) {
-            double s = 0.0;
-            if (tid < 27) {
-                s = red[tid];
-#pragma unroll
-                for (int q = 1; q < RED_PARTS; ++q) s += red[q * 27 + tid];      // the same order as k_cam_reduce_tree: bitwise the same sums
-                partial[(size_t)c * 27 + tid] = s;
-            }
+            if (tid < 27) partial[(size_t)c * 27 + tid] = s;
             peer_push_row(peer, c, s, tid);
         }
         __syncthreads();                                     // sh is overwritten by the next camera
@@ -507,7 +505,6 @@ struct FusedPlan {
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     size_t shmem = 0;
     FusedArgs args{};
-    const int *d_blk = nullptr;
     int *d_big = nullptr;
     std::vector<void *> allocs;
     void *(*alloc)(void *ctx, size_t bytes) = nullptr;   // optional: take device memory from the owner's arena (else hipMalloc)
@@ -569,10 +566,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     pl.pass_shmem = sizeof(double) * (size_t)(((pl.pass_cams * 27 + 1) & ~1) + 2);
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
-    std::vector<int32_t> blk((size_t)pl.n_blocks + 1);
-    for (int b = 0; b <= pl.n_blocks; ++b) blk[b] = (int32_t)((int64_t)b * p.T / pl.n_blocks);
-    int *d_blk = nullptr; double *d_bp = nullptr;
-    if (fused_upload(pl, &d_blk, blk.data(), blk.size(), stream)) return -1;
+    double *d_bp = nullptr;                                 // (workgroup b walks tiles [b T / n_blocks, (b + 1) T / n_blocks): computed in the kernels)
     if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * TROW, stream)) return -1;
     pl.n_big = (int)big.size();
     if (pl.n_big && fused_upload(pl, &pl.d_big, big.data(), big.size(), stream)) return -1;
@@ -582,7 +576,6 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
 #endif
     pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, env_dbg ? atoi(env_dbg) : 0, d_phase, nullptr};
-    pl.d_blk = d_blk;
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
@@ -591,10 +584,6 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     if (pl.n_groups > 1 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_pass<PASS_WAVES>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pass_shmem) != hipSuccess) return -1;
 #undef GBP_SET_SHMEM
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_reduce_xchg), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27))) != hipSuccess) return -1;
     pl.enabled = true;
     return 0;
 }
@@ -611,9 +600,9 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
     if (e0) (void)hipEventRecord(e0, stream);
     switch (p.loss) {
-    case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles, pl.d_blk); break;
-    case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles, pl.d_blk); break;
-    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles, pl.d_blk); break;
+    case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
     for (int g = 1; g < pl.n_groups; ++g) {                 // the messages to the cameras of the further groups (C > 516)
@@ -621,10 +610,10 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
         ag.cam_base = pl.group_cams + (g - 1) * pl.pass_cams;
         ag.cam_count = std::min(p.C - ag.cam_base, pl.pass_cams);
         ag.acc_doubles = ag.cam_count * 27;
-        hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.pass_shmem, stream, p, ag, p.tiles, pl.d_blk);
+        hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.pass_shmem, stream, p, ag, p.tiles);
     }
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
-    const size_t red_shmem = sizeof(double) * ((size_t)(pl.n_blocks * TROW) + (RED_PARTS + 1) * 27);
+    const size_t red_shmem = 0;                             // (static LDS)
     PeerOut po{};
     if (peer) po = *peer;
     if (merged && peer) {                                   // reduce -> push -> wait -> finish in one launch (peer-store exchange)

@@ -23,12 +23,13 @@
 // Lambda_f / eta_f (90 doubles per factor in the reference) are never stored: they are rebuilt from x0 and z
 // every sweep (2x9 Jacobian ~ 150 flops versus 720 bytes of traffic).
 //
-// A factor reads a belief as MEAN | COVARIANCE (gbp_math.hpp: covariance form); eta | Lambda are kept beside them for the views.
-// Landmarks: array of records lrec[L][30] = mu 3 | Sigma 6 | {first slot, end slot} as two int32 | prior (eta 3 | Lambda 6) | pad |
-//            belief (eta 3 | Lambda 6) | pad.  A tile's landmarks are consecutive records.
-// Cameras:   cbel[C][56] = mu 6 | Sigma 21 | pad | eta 6 | Lambda 21 | pad (the first 224 bytes are gathered per factor,
-//            L2-resident: 500 cams = 112 KB), cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of each camera's
-//            factors (reference order).
+// A factor reads a belief as MEAN | COVARIANCE (gbp_math.hpp: covariance form).
+// Landmarks: array of records lrec[L][20] = mu 3 | Sigma 6 | {first slot, end slot} as two int32 | prior (eta 3 | Lambda 6) | pad.
+//            A tile's landmarks are consecutive records.  Their eta | Lambda (a view: VariableNode.belief) is formed from mean |
+//            covariance when it is asked for (k_lmk_belief_view): 72 bytes per landmark and sweep that no kernel reads.
+// Cameras:   cbel[C][32] = mu 6 | Sigma 21 | pad (224 bytes gathered per factor, L2-resident: 500 cams = 128 KB),
+//            cbelief[C][28] = eta 6 | Lambda 21 | pad (views), cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of
+//            each camera's factors (reference order).
 //
 // General sweep (any shape) = k_factor_tile (one wave per tile: messages, the tile's landmark beliefs, camera messages
 // staged in camera-major order) -> k_lmk_belief_list (landmarks larger than a tile) -> k_cam_partial_staged (one
@@ -45,12 +46,13 @@ constexpr int LIN_ROWS = 12, MSG_ROWS = 10;
 constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_AVAR = 11;
 constexpr int ROW_QC = 0, ROW_QL = 2, ROW_WC = 4, ROW_VL = 7;
 constexpr int XTRA_ROW = 9;       // doubles per slot of the dense remainder (num_undamped_iters = 0 only): camera 6 | landmark 3
-constexpr int LREC = 30;          // doubles per landmark record: mu 3 | Sigma 6 | rows | prior 9 | pad | belief 9 | pad
-constexpr int LR_MU = 0, LR_COV = 3, LR_ROWS = 9, LR_PRIOR = 10, LR_BEL = 20;
+constexpr int LREC = 20;          // doubles per landmark record: mu 3 | Sigma 6 | rows | prior 9 | pad
+constexpr int LR_MU = 0, LR_COV = 3, LR_ROWS = 9, LR_PRIOR = 10;
 constexpr int LHEAD = 10;         // ... of which a factor reads the first ten (mean | covariance | rows)
-constexpr int CAMREC = 56;        // doubles per camera record: mu 6 | Sigma 21 | pad | eta 6 | Lambda 21 | pad
-constexpr int CAM_MU = 0, CAM_COV = 6, CAM_ETA = 28, CAM_LAM = 34;
-constexpr int CAMHEAD = 28;       // ... of which a factor gathers the first 28 (mean | covariance): 14 x 16 bytes
+constexpr int CAMREC = 32;        // doubles per camera record: mu 6 | Sigma 21 | pad (256 bytes: a record is exactly two 128-byte lines)
+constexpr int CAM_MU = 0, CAM_COV = 6;
+constexpr int CAMHEAD = 28;       // ... of which a factor gathers 28 (mean | covariance): 14 x 16 bytes
+constexpr int CBEL = 28;          // doubles per row of cbelief: eta 6 | Lambda 21 | pad (views, checkpoints; no sweep kernel reads it)
 constexpr int META_LMK_BITS = 8;   // meta = camera << 8 | landmark slot.  (camera in the LOW bits + '& 0xffffff' was
                                    // miscompiled by hipcc 7.2: the mask vanished in front of a v_mad_u64_u32 address multiply)
 constexpr int BLOCK = 256;
@@ -70,7 +72,7 @@ struct Params {
     const unsigned *meta;
     const int4 *tiles;            // {first landmark, landmarks owned, slots used, max rank}
     double *lrec;
-    double *cbel, *cprior;
+    double *cbel, *cprior, *cbelief;
     const int *cptr, *cadj;
     double *cstage;               // general sweep: [F][crow] what rebuilds the camera messages, in camera-major (reference) order, or NULL
     int crow;                     // doubles per staged row: CSTAGE_PLAIN, or CSTAGE_ROW with xtra
@@ -368,7 +370,8 @@ GBP_DEV void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// A landmark belief from its eta | Lambda (b), written in both forms: mean | covariance for the factors, eta | Lambda for the views
+// A landmark belief from its eta | Lambda (b), in the form the factors read it: mean | covariance (VariableNode.update_belief
+// gbp.py:189-193 plus the inverse, gbp_math.hpp)
 GBP_DEV void lmk_belief_store(const double (&b)[9], double *__restrict__ lr)
 {
     double eta[3] = {b[0], b[1], b[2]}, lam[6] = {b[3], b[4], b[5], b[6], b[7], b[8]}, mu[3], sig[6];
@@ -377,9 +380,6 @@ GBP_DEV void lmk_belief_store(const double (&b)[9], double *__restrict__ lr)
     d0[0] = make_double2(mu[0], mu[1]); d0[1] = make_double2(mu[2], sig[0]);
     d0[2] = make_double2(sig[1], sig[2]); d0[3] = make_double2(sig[3], sig[4]);
     lr[LR_COV + 5] = sig[5];                                 // (the double behind it holds the landmark's slot range)
-    double2 *d1 = reinterpret_cast<double2 *>(lr + LR_BEL);
-    d1[0] = make_double2(b[0], b[1]); d1[1] = make_double2(b[2], b[3]); d1[2] = make_double2(b[4], b[5]);
-    d1[3] = make_double2(b[6], b[7]); d1[4] = make_double2(b[8], 0.0);
 }
 
 // What the belief phase of a tile needs besides the messages, fetched ahead of it: nine lanes per landmark add one belief entry
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *
     if (!finish) return;
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) rec[CAM_ETA + threadIdx.x - 64] = tot[threadIdx.x - 64];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) p.cbelief[(size_t)c * CBEL + threadIdx.x - 64] = tot[threadIdx.x - 64];
     if (threadIdx.x < 7) {
         double v[27];
 #pragma unroll
@@ -617,10 +617,9 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *
 // ------------------------------------------------------------------ general sweep, stage 2 --
 // VariableNode.update_belief for one landmark (gbp.py:176-198): prior + messages in adj_factors order
 // (= ascending reference factor id = slot order inside the landmark), then mu = Lambda^-1 eta.
-GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
+GBP_DEV void landmark_sum_from_hbm(const Params &p, int l, double (&acc)[9])
 {
-    double *lr = p.lrec + (size_t)l * LREC;
-    double acc[9];
+    const double *lr = p.lrec + (size_t)l * LREC;
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = lr[LR_PRIOR + k];
     const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
@@ -632,7 +631,35 @@ GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[3 + k] += ML[k];
     }
-    lmk_belief_store(acc, lr);
+}
+
+GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
+{
+    double acc[9];
+    landmark_sum_from_hbm(p, l, acc);
+    lmk_belief_store(acc, p.lrec + (size_t)l * LREC);
+}
+
+// VariableNode.belief (eta | Lambda) of every landmark as a view.  The sweep keeps a landmark belief in the form the factors read,
+// mean | covariance; its information form is Lambda = Sigma^-1, eta = Lambda mu -- the belief as of the last update_belief, whatever has
+// happened to messages or priors since (the stage-wise calls of gbp.py:46-84 change those without touching the beliefs).  The 3x3
+// round trip costs ~cond(Lambda) * 1e-16 relative (1e-10 on the shipped data) against 72 bytes per landmark and sweep that no kernel reads.
+__global__ __launch_bounds__(BLOCK) void k_lmk_belief_view(Params p, double *__restrict__ out)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l >= p.L) return;
+    const double *lr = p.lrec + (size_t)l * LREC;
+    double sig[6], lam[6], mu[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sig[k] = lr[LR_COV + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mu[k] = lr[LR_MU + k];
+    spd_inverse<3>(sig, lam);
+    out[(size_t)l * 9 + 0] = lam[0] * mu[0] + lam[1] * mu[1] + lam[2] * mu[2];
+    out[(size_t)l * 9 + 1] = lam[1] * mu[0] + lam[3] * mu[1] + lam[4] * mu[2];
+    out[(size_t)l * 9 + 2] = lam[2] * mu[0] + lam[4] * mu[1] + lam[5] * mu[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[(size_t)l * 9 + 3 + k] = lam[k];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
@@ -772,7 +799,7 @@ GBP_DEV void cam_finish_wave(const Params &p, const double *gathered, int n_part
         acc = p.cprior[(size_t)c * 27 + lane];
         for (int r = 0; r < n_parts; ++r) acc += gathered[(size_t)r * part_stride + (size_t)c * 27 + lane];
     }
-    if (lane < 27) p.cbel[(size_t)c * CAMREC + CAM_ETA + lane] = acc;
+    if (lane < 27) p.cbelief[(size_t)c * CBEL + lane] = acc;
     double v[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) v[k] = __shfl(acc, k, 64);
@@ -1064,22 +1091,14 @@ __global__ __launch_bounds__(BLOCK) void k_pack_means(Params p, double *__restri
 
 __global__ __launch_bounds__(BLOCK) void k_covariances(Params p, double *__restrict__ cam_sig, double *__restrict__ lmk_sig)
 {
-    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    const int v = blockIdx.x * BLOCK + threadIdx.x;          // (the beliefs carry their covariances: gbp_math.hpp, covariance form)
     if (v < p.C) {
-        double lam[21], sig[21];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) lam[k] = p.cbel[(size_t)v * CAMREC + CAM_LAM + k];
-        spd_inverse<6>(lam, sig);
-#pragma unroll
-        for (int k = 0; k < 21; ++k) cam_sig[(size_t)v * 21 + k] = sig[k];
+        for (int k = 0; k < 21; ++k) cam_sig[(size_t)v * 21 + k] = p.cbel[(size_t)v * CAMREC + CAM_COV + k];
     } else if (v < p.C + p.L) {
         const int l = v - p.C;
-        double lam[6], sig[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) lam[k] = p.lrec[(size_t)l * LREC + LR_BEL + 3 + k];
-        spd_inverse<3>(lam, sig);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) lmk_sig[(size_t)l * 6 + k] = sig[k];
+        for (int k = 0; k < 6; ++k) lmk_sig[(size_t)l * 6 + k] = p.lrec[(size_t)l * LREC + LR_COV + k];
     }
 }
 
