@@ -131,6 +131,25 @@ GBP_DEV void st2(double *__restrict__ base, unsigned byte_off, double x, double 
 }
 GBP_DEV void st1(double *__restrict__ base, unsigned byte_off, double x) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off) = x; }
 
+// everything a tile's factors stream: six + five row pairs of the tile's block (16 bytes per lane each), the meta and state words
+struct TileStreams {
+    double2 a[6], m[5];
+    unsigned meta;
+    int st;
+};
+GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s)
+{
+    const double *lin_t = p.lin + (size_t)t * (LIN_ROWS * WTILE);
+    const double *msg_t = p.msg + (size_t)t * (MSG_ROWS * WTILE);
+    const unsigned lo = (unsigned)lane * 16u;             // byte offset of this lane's 16 bytes inside a row pair (1 KB per pair)
+    s.meta = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.meta + (size_t)t * WTILE) + (unsigned)lane * 4u);
+    s.st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s.a[k] = ld2(lin_t, 1024u * k + lo);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s.m[k] = ld2(msg_t, 1024u * k + lo);
+}
+
 template <int LOSS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
@@ -161,6 +180,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     GBP_PH_DECL;
 
     const int lane_entry = lane;
+    TileStreams S;
     for (;;) {
         GBP_PH_NOWAIT(9);                                  // loop overhead / after the release of the accumulation ticket
         // Everything the loop derives from the lane index (LDS offsets of the belief phase, stream offsets, ...) is two or three
@@ -174,12 +194,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         ti = __builtin_amdgcn_readfirstlane(ti);
         const bool valid = ti < ntl;
         const int t = tb + (valid ? (a.reverse ? ntl - 1 - ti : ti) : 0);
-#ifdef GBP_DESC_FIRST                                      // A/B: the descriptor's round trip in front of the streams (rounds 1-3)
-        const int4 td = tiles[valid ? t : tb];
-        const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
-        const bool active = lane < nf;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         GBP_PH(0);                                         // ticket
         if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
             if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
@@ -187,34 +201,25 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             break;
         }
 
-        // everything the factor streams: six + five row pairs of the tile's block, 16 bytes per lane each
+        // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        const double *lin_t = p.lin + (size_t)t * (LIN_ROWS * WTILE);
-        const double *msg_t = p.msg + (size_t)t * (MSG_ROWS * WTILE);
-        const unsigned lo = (unsigned)lane * 16u;         // byte offset of this lane's 16 bytes inside a row pair (1 KB per pair)
+        issue_streams(p, t, lane, S);
+        const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
-        const unsigned meta = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.meta + (size_t)t * WTILE) + (unsigned)lane * 4u);
-        int st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u);
-        {
-            const double2 a0 = ld2(lin_t, lo), a1 = ld2(lin_t, 1024u + lo), a2 = ld2(lin_t, 2048u + lo), a3 = ld2(lin_t, 3072u + lo),
-                          a4 = ld2(lin_t, 4096u + lo), a5 = ld2(lin_t, 5120u + lo);
-            const double2 m0 = ld2(msg_t, lo), m1 = ld2(msg_t, 1024u + lo), m2 = ld2(msg_t, 2048u + lo), m3 = ld2(msg_t, 3072u + lo),
-                          m4 = ld2(msg_t, 4096u + lo);
-            x0[0] = a0.x; x0[1] = a0.y; x0[2] = a1.x; x0[3] = a1.y; x0[4] = a2.x; x0[5] = a2.y; x0[6] = a3.x; x0[7] = a3.y;
-            x0[8] = a4.x; z[0] = a4.y; z[1] = a5.x;
-            if (LOSS != 0) avar = a5.y;
-            qC[0] = m0.x; qC[1] = m0.y; qL[0] = m1.x; qL[1] = m1.y;
-            WC[0] = m2.x; WC[1] = m2.y; WC[2] = m3.x; VL[0] = m3.y; VL[1] = m4.x; VL[2] = m4.y;
-        }
+        const unsigned meta = S.meta;
+        int st = S.st;
+        x0[0] = S.a[0].x; x0[1] = S.a[0].y; x0[2] = S.a[1].x; x0[3] = S.a[1].y; x0[4] = S.a[2].x; x0[5] = S.a[2].y; x0[6] = S.a[3].x; x0[7] = S.a[3].y;
+        x0[8] = S.a[4].x; z[0] = S.a[4].y; z[1] = S.a[5].x;
+        if (LOSS != 0) avar = S.a[5].y;
+        qC[0] = S.m[0].x; qC[1] = S.m[0].y; qL[0] = S.m[1].x; qL[1] = S.m[1].y;
+        WC[0] = S.m[2].x; WC[1] = S.m[2].y; WC[2] = S.m[3].x; VL[0] = S.m[3].y; VL[1] = S.m[4].x; VL[2] = S.m[4].y;
         // the tile's descriptor, and the heads (mean | covariance | rows) of its landmark records: ten doubles of every twenty,
         // fetched by the whole wave.  (Behind the streams, which need nothing but the tile index: the descriptor's round trip
         // overlaps theirs instead of preceding it.)
-#ifndef GBP_DESC_FIRST
         const int4 td = tiles[t];
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
-#endif
         const int nhead2 = max(nl, 1) * (LHEAD / 2);       // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
         const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
         constexpr int NSTAGE = (TILE_LMKS * (LHEAD / 2) + 63) / 64;
