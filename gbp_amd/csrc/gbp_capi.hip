@@ -75,7 +75,7 @@ struct gbp_ba {
     int *d_big = nullptr;                        // the same on the device (general sweep)
     bool hash_ok = false; uint64_t hash = 0;     // digest of the layout (state blobs)
     void *arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
-    std::vector<void *> snap; bool snap_has_beliefs = false; uint32_t snap_parity = 0;   // device-resident checkpoint (gbp_ba_snapshot_state)
+    std::vector<void *> snap; std::vector<size_t> snap_bytes; bool snap_has_beliefs = false; uint32_t snap_parity = 0;   // device-resident checkpoint (gbp_ba_snapshot_state)
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -83,6 +83,10 @@ struct gbp_ba {
     std::vector<void *> allocs;
     bool has_beliefs = false;
     bool pending_possible = false;               // a stage-wise relinearise / compute_factors has run since the messages were last computed
+    // dense message remainder allocated on demand (a damped factor that moves its linearisation point: enable_remainder)
+    double *xtra_buf = nullptr;                  // the allocation behind p.xtra when it was made after create
+    bool lazy_xtra = false, fused_suspended = false;
+    long lazy_since = 0;                         // sweeps run since the remainder was switched on (it is checked for all-zero every 16)
     bool resid_ok = false; double resid[2] = {0.0, 0.0};     // ARE / energy sums of the CURRENT state (ba.py asks for both every sweep)
     // streaming means export (viewer): device staging, two pinned host mirrors, a copy stream
     double *d_mu = nullptr, *h_mu[2] = {nullptr, nullptr};
@@ -884,6 +888,66 @@ int gbp_ba_weaken_priors(gbp_ba_t *h, double factor)
 
 // -------------------------------------------------------------------------------- sweep ---
 
+// ---- the dense message remainder on demand -------------------------------------------------------------------------------
+// A message is stored as coefficients in the rows of its factor's Jacobian (gbp_math.hpp).  The one thing that does not fit is a
+// factor that is DAMPED in the message computation that moves its linearisation point: d * (old eta) lies in the span of the OLD
+// Jacobian.  The reference allows it at any time (compute_all_factors with damping on, gbp.py:60-62; relinearise_factors followed by
+// compute_all_messages(local_relin=False), gbp.py:46-54); graphs created with num_undamped_iters = 0 carry the out-of-span part
+// from the start (Params::xtra, 9 doubles per factor), every other graph gets it HERE, the first time such a call sequence
+// shows up, and runs the general sweep (the kernels with the XTRA template flag) until every remainder has decayed to exactly
+// zero again -- which the next undamped message of a factor does (x' = d x), i.e. after the next relinearisation wave.
+static inline size_t n_slots(const gbp_ba *h);
+static int enable_remainder(gbp_ba *h)
+{
+    Params &p = h->p;
+    if (p.xtra) return GBP_OK;
+    const size_t n = n_slots(h) * XTRA_ROW;
+    if (!h->xtra_buf) {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->xtra_buf), n * sizeof(double)));
+        h->allocs.push_back(h->xtra_buf);
+    }
+    HIPCHK(hipMemsetAsync(h->xtra_buf, 0, n * sizeof(double), h->stream));
+    p.xtra = h->xtra_buf;
+    if (p.crow != CSTAGE_ROW) { p.crow = CSTAGE_ROW; p.cstage = nullptr; }      // staged rows carry the remainder too: a wider buffer (ensure_staging)
+    h->lazy_xtra = true; h->lazy_since = 0;
+    h->fused_suspended = h->fused.enabled;
+    h->fused.enabled = false;
+    h->dominant = "k_factor_tile";
+    return GBP_OK;
+}
+
+// before a message computation: does a pending relinearisation meet a non-zero damping?  (only after stage-wise calls, state loads)
+static int remainder_guard(gbp_ba *h, int local_relin, int no_test)
+{
+    if (!h->pending_possible || h->p.xtra || h->p.eta_damping == 0.0 || !h->p.T) return GBP_OK;
+    HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_count_pending_damped, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, local_relin, no_test, h->d_count);
+    HIPCHK(hipGetLastError());
+    int c = 0;
+    HIPCHK(hipMemcpyAsync(&c, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (c) CHK(enable_remainder(h));
+    return GBP_OK;
+}
+
+// after a sweep on a remainder that was switched on on demand: back to the fused sweep once nothing is left of it
+static int remainder_release(gbp_ba *h)
+{
+    if (!h->lazy_xtra || !h->p.xtra || (++h->lazy_since & 15) != 0) return GBP_OK;
+    const size_t n = n_slots(h) * XTRA_ROW;
+    HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_count_nonzero, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p.xtra, n, h->d_count);
+    HIPCHK(hipGetLastError());
+    int c = 0;
+    HIPCHK(hipMemcpyAsync(&c, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (c) return GBP_OK;
+    h->p.xtra = nullptr;                                     // (the buffer stays for the next time)
+    h->lazy_xtra = false;
+    if (h->fused_suspended) { h->fused.enabled = true; h->dominant = "k_sweep_fused"; }
+    return GBP_OK;
+}
+
 int gbp_ba_update_beliefs(gbp_ba_t *h)
 {
     ENTER(h);
@@ -900,9 +964,12 @@ int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t loca
     h->resid_ok = false;
     if (n_iters < 0) return fail(GBP_EINVAL, "n_iters < 0");
     for (int it = 0; it < n_iters; ++it) {
+        CHK(remainder_guard(h, local_relin, 0));
         bool finished = false;
         CHK(sweep_begin(h, 1, robustify, local_relin, h->d_partial, 1, &finished));
         if (!finished) CHK(launch_cam_finish(h, h->d_partial, 1, 0));
+        h->pending_possible = false;                         // every pending relinearisation has been applied
+        CHK(remainder_release(h));
     }
     h->has_beliefs = true;
     return GBP_OK;
@@ -926,16 +993,6 @@ int gbp_ba_robustify(gbp_ba_t *h)
     return GBP_OK;
 }
 
-static int stage_counts(gbp_ba *h, int out2[2])
-{
-    HIPCHK(hipMemsetAsync(h->d_count, 0, 2 * sizeof(int), h->stream));
-    if (h->p.T) hipLaunchKernelGGL(k_count_pending, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, h->d_count);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out2, h->d_count, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return GBP_OK;
-}
-
 int gbp_ba_relinearise(gbp_ba_t *h)
 {
     ENTER(h);
@@ -952,13 +1009,8 @@ int gbp_ba_compute_factors(gbp_ba_t *h)
     ENTER(h);
     h->resid_ok = false;
     if (!h->has_beliefs) return fail(GBP_ESTATE, "compute_all_factors linearises at the belief means: call update_all_beliefs first");
-    if (!h->p.xtra) {
-        // a factor that moves its linearisation point while its eta damping is on leaves the span its message coefficients live in
-        int c[2];
-        CHK(stage_counts(h, c));
-        if (c[1]) return fail(GBP_ESTATE, "compute_all_factors while %d factors are damped needs the dense message remainder: create the graph with "
-                                           "num_undamped_iters = 0 (or call it before any damping is on)", c[1]);
-    }
+    // (a factor that is damped when it moves leaves the span its message coefficients live in: the message computation that applies
+    //  the move checks for that and switches the dense remainder on, remainder_guard)
     if (h->p.T) hipLaunchKernelGGL(k_stage_relinearise, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, 1);
     HIPCHK(hipGetLastError());
     h->pending_possible = true;
@@ -970,12 +1022,7 @@ int gbp_ba_compute_messages(gbp_ba_t *h, int32_t local_relin)
     ENTER(h);
     h->resid_ok = false;
     if (!h->has_beliefs) return fail(GBP_ESTATE, "compute_all_messages needs beliefs (call update_all_beliefs first)");
-    if (h->pending_possible && !local_relin && !h->p.xtra && h->p.eta_damping != 0.0) {
-        int c[2];
-        CHK(stage_counts(h, c));
-        if (c[0]) return fail(GBP_ESTATE, "compute_all_messages(local_relin=False) damps %d factors in the call that relinearises them: that needs the dense "
-                                           "message remainder (create the graph with num_undamped_iters = 0)", c[0]);
-    }
+    CHK(remainder_guard(h, local_relin, 1));
     const int slot = (int)(h->sweep_count % RELIN_RING);
     if (slot % (RELIN_RING / 2) == 0)
         HIPCHK(hipMemsetAsync(h->d_relin_ring + (size_t)slot * RELIN_LANES, 0, sizeof(int) * (RELIN_RING / 2) * RELIN_LANES, h->stream));
@@ -994,7 +1041,10 @@ int gbp_ba_shard_begin(gbp_ba_t *h, int32_t with_messages, int32_t robustify, in
     ENTER(h);
     h->resid_ok = false;
     if (!partial_dev) return fail(GBP_EINVAL, "null partial buffer");
-    return sweep_begin(h, with_messages, robustify, local_relin, partial_dev);
+    if (with_messages) CHK(remainder_guard(h, local_relin, 0));
+    CHK(sweep_begin(h, with_messages, robustify, local_relin, partial_dev));
+    if (with_messages) { h->pending_possible = false; CHK(remainder_release(h)); }
+    return GBP_OK;
 }
 
 int gbp_ba_shard_end(gbp_ba_t *h, const double *gathered_dev, int32_t n_ranks)
@@ -1021,6 +1071,7 @@ int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank
     ENTER(h);
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GBP_EINVAL, "rank %d of %d", rank, n_ranks);
     if (!fn && n_ranks > 1) return fail(GBP_EINVAL, "an exchange function is needed for more than one rank");
+    peer_release(h);                                         // (a connected peer-store exchange would keep routing the sweeps)
     shard_comm_release(h);
     CHK(shard_buffers(h, n_ranks));
     h->xch_fn = fn; h->xch_ctx = ctx; h->xch_rank = rank; h->xch_ranks = n_ranks; h->xch_flags = flags;
@@ -1044,6 +1095,7 @@ int gbp_ba_comm_init_rccl(gbp_ba_t *h, const void *id128, int32_t rank, int32_t 
     ENTER(h);
     if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GBP_EINVAL, "bad communicator arguments (rank %d of %d)", rank, n_ranks);
     CHK(rccl_load(rccl_path));
+    peer_release(h);
     shard_comm_release(h);
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
@@ -1059,7 +1111,9 @@ int gbp_ba_comm_destroy(gbp_ba_t *h)
     ENTER(h);
     shard_comm_release(h);
     peer_release(h);
-    return GBP_OK;
+    h->xch_fn = nullptr; h->xch_ctx = nullptr; h->xch_ranks = 1; h->xch_rank = 0;
+    if (h->d_send) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_send); (void)hipFree(h->d_recv); h->d_send = h->d_recv = nullptr; }
+    return GBP_OK;                                           // (gbp_ba_iterate_sharded now reports "no exchange set" instead of running on stale buffers)
 }
 
 int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t flags)
@@ -1071,8 +1125,21 @@ int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t fla
     if (pe.mailbox) { HIPCHK(hipFree(pe.mailbox)); pe.mailbox = nullptr; }
     const size_t bytes = peer_bytes(h, n_ranks);
     // fine-grained (uncached across devices) when the runtime grants it: peers store into it over xGMI while this rank polls it
-    pe.finegrained = !getenv("GBP_PEER_COARSE") && hipExtMallocWithFlags(&pe.mailbox, bytes, hipDeviceMallocFinegrained) == hipSuccess;
-    if (!pe.finegrained) { (void)hipGetLastError(); HIPCHK(hipMalloc(&pe.mailbox, bytes)); }
+    // Fine-grained (uncached across devices): peers store into it over xGMI while this rank polls it, and the protocol has no fences --
+    // on coarse-grained pages a polling load may keep hitting a stale L2 line.  No silent fallback: GBP_PEER_COARSE=1 is a debug switch
+    // for ranks that share ONE device.
+    if (getenv("GBP_PEER_COARSE")) {
+        pe.finegrained = false;
+        HIPCHK(hipMalloc(&pe.mailbox, bytes));
+    } else {
+        const hipError_t fe = hipExtMallocWithFlags(&pe.mailbox, bytes, hipDeviceMallocFinegrained);
+        if (fe != hipSuccess) {
+            (void)hipGetLastError();
+            pe.mailbox = nullptr;
+            return fail(GBP_EHIP, "peer exchange: fine-grained device memory for the mailbox is not available (%s); use the RCCL exchange", hipGetErrorString(fe));
+        }
+        pe.finegrained = true;
+    }
     HIPCHK(hipMemsetAsync(pe.mailbox, 0, bytes, h->stream));
     if (!pe.d_ctl) HIPCHK(hipMalloc(reinterpret_cast<void **>(&pe.d_ctl), 2 * sizeof(int)));
     HIPCHK(hipMemsetAsync(pe.d_ctl, 0, 2 * sizeof(int), h->stream));
@@ -1115,7 +1182,9 @@ int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *
     pe.rank = rank;
     double ms = 20000.0;                                     // how long a finish kernel waits for a peer before it gives up
     if (const char *e = getenv("GBP_PEER_TIMEOUT_MS")) ms = std::max(1.0, atof(e));
-    pe.timeout_ticks = (long long)(ms * 1e5);                // wall_clock64: 100 MHz
+    int clk_khz = 0;
+    if (hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || clk_khz <= 0) clk_khz = 100000;
+    pe.timeout_ticks = (long long)(ms * (double)clk_khz);    // wall_clock64 ticks (100 MHz on MI355X)
     if (!(flags & GBP_PEER_RENDEZVOUS)) { h->xch_fn = nullptr; h->xch_ctx = nullptr; }
     h->xch_rank = rank; h->xch_ranks = n_ranks;
     pe.connected = true;
@@ -1199,7 +1268,12 @@ int gbp_ba_iterate_sharded(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int3
     h->resid_ok = false;
     if (n_iters < 0) return fail(GBP_EINVAL, "n_iters < 0");
     if (!h->d_send) return fail(GBP_ESTATE, "no exchange set (gbp_ba_comm_init_rccl / gbp_ba_set_exchange / gbp_ba_peer_connect)");
-    for (int it = 0; it < n_iters; ++it) CHK(sharded_step(h, 1, robustify, local_relin));
+    for (int it = 0; it < n_iters; ++it) {
+        CHK(remainder_guard(h, local_relin, 0));
+        CHK(sharded_step(h, 1, robustify, local_relin));
+        h->pending_possible = false;
+        CHK(remainder_release(h));
+    }
     h->has_beliefs = true;
     return GBP_OK;
 }
@@ -1582,7 +1656,7 @@ namespace {
 struct StateHeader {
     char magic[8];                 // "GBPSTATE"
     uint32_t version, has_beliefs;
-    uint32_t walk_parity, reserved;
+    uint32_t walk_parity, reserved;    // reserved: bit 0 = the blob carries the dense message remainder
     int32_t F, T, L, C;
     uint64_t graph_hash;           // digest of the factor -> (slot, camera, landmark) maps (k_graph_hash)
     uint64_t payload_bytes;
@@ -1637,7 +1711,7 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
     hd.version = 5; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
-    hd.walk_parity = h->walk_parity; hd.reserved = 0;
+    hd.walk_parity = h->walk_parity; hd.reserved = h->p.xtra ? 1u : 0u;      // (1: the payload ends with the dense message remainder)
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
     CHK(graph_hash(h, &hd.graph_hash));
     hd.payload_bytes = need - sizeof(StateHeader);
@@ -1658,17 +1732,28 @@ int gbp_ba_snapshot_state(gbp_ba_t *h)
 {
     ENTER(h);
     std::vector<StatePart> parts = state_parts(h);
-    if (h->snap.empty()) {
-        for (const StatePart &q : parts) {
-            void *d = nullptr;
-            if (q.bytes) HIPCHK(hipMalloc(&d, q.bytes));
-            h->snap.push_back(d);
+    h->snap.resize(parts.size(), nullptr);
+    h->snap_bytes.resize(parts.size(), 0);
+    for (size_t i = 0; i < parts.size(); ++i) {
+        if (h->snap_bytes[i] != parts[i].bytes) {           // (the remainder may have appeared or gone since the last snapshot)
+            if (h->snap[i]) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->snap[i])); h->snap[i] = nullptr; }
+            if (parts[i].bytes) HIPCHK(hipMalloc(&h->snap[i], parts[i].bytes));
+            h->snap_bytes[i] = parts[i].bytes;
         }
-    }
-    for (size_t i = 0; i < parts.size(); ++i)
         if (parts[i].bytes) HIPCHK(hipMemcpyAsync(h->snap[i], parts[i].dev, parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
     h->snap_has_beliefs = h->has_beliefs;
     h->snap_parity = h->walk_parity;
+    return GBP_OK;
+}
+
+// a handle whose remainder was switched on on demand goes back to the state "no remainder" (a checkpoint without one is restored)
+static int remainder_drop(gbp_ba *h)
+{
+    if (!h->lazy_xtra || !h->p.xtra) return GBP_OK;
+    h->p.xtra = nullptr;
+    h->lazy_xtra = false;
+    if (h->fused_suspended) { h->fused.enabled = true; h->dominant = "k_sweep_fused"; }
     return GBP_OK;
 }
 
@@ -1677,9 +1762,14 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h)
     ENTER(h);
     h->resid_ok = false;
     if (h->snap.empty()) return fail(GBP_ESTATE, "no snapshot taken (gbp_ba_snapshot_state)");
+    const size_t ix = h->snap.size() - 1;                    // the remainder is the last part
+    if (h->snap_bytes[ix] && !h->p.xtra) CHK(enable_remainder(h));
+    if (!h->snap_bytes[ix] && h->p.xtra) CHK(remainder_drop(h));
     std::vector<StatePart> parts = state_parts(h);
-    for (size_t i = 0; i < parts.size(); ++i)
+    for (size_t i = 0; i < parts.size(); ++i) {
+        if (parts[i].bytes != h->snap_bytes[i]) return fail(GBP_ESTATE, "the snapshot does not fit the handle any more (part %zu)", i);
         if (parts[i].bytes) HIPCHK(hipMemcpyAsync(parts[i].dev, h->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
     h->has_beliefs = h->snap_has_beliefs;
     h->pending_possible = true;                              // (the restored state words may carry pending relinearisations)
     h->walk_parity = h->snap_parity;
@@ -1690,12 +1780,19 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
 {
     ENTER(h);
     h->resid_ok = false;
-    uint64_t need = 0;
-    CHK(gbp_ba_state_size(h, &need));
     if (!buf || bytes < sizeof(StateHeader)) return fail(GBP_EINVAL, "state buffer too small for a header");
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
     if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0) return fail(GBP_EINVAL, "not a GBP state blob (magic)");
+    if (hd.version == 5 && hd.F == h->p.F && hd.T == h->p.T) {      // the blob decides whether the handle carries a remainder
+        if ((hd.reserved & 1u) && !h->p.xtra) CHK(enable_remainder(h));
+        if (!(hd.reserved & 1u) && h->p.xtra) {
+            if (!h->lazy_xtra) return fail(GBP_EINVAL, "the state blob has no dense message remainder but this graph always carries one (num_undamped_iters = 0)");
+            CHK(remainder_drop(h));
+        }
+    }
+    uint64_t need = 0;
+    CHK(gbp_ba_state_size(h, &need));
     if (hd.version != 5)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances (records of 24 / 34 doubles)
         return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 5; INTEGRATION.md)", hd.version);
     uint64_t mine = 0;

@@ -1023,18 +1023,34 @@ __global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_
     p.state[slot] = state_pack(iters, state_rank(st), (st & 2) != 0, damped, pending);
 }
 
-// {factors with a pending relinearisation, factors that are damped}: what decides whether a deferred relinearisation is exact
-__global__ __launch_bounds__(BLOCK) void k_count_pending(Params p, int *__restrict__ out2)
+// How many factors would be DAMPED in the very message computation that moves their linearisation point -- a pending relinearisation
+// (stage-wise relinearise_factors / compute_all_factors) met by a non-zero eta damping -- if the messages were computed now with
+// these flags?  Such a message has a part outside the span of the new Jacobian, which only the dense remainder (Params::xtra) can
+// carry; the host allocates it when this count is non-zero (gbp_capi.hip: enable_remainder).  Mirrors factor_decide.
+__global__ __launch_bounds__(BLOCK) void k_count_pending_damped(Params p, int local_relin, int no_test, int *__restrict__ out)
 {
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
     int cam, lmk;
-    const bool live = slot < p.T * WTILE && slot_info(p, slot, cam, lmk);
-    const int st = live ? p.state[slot] : 0;
-    const unsigned long long a = __ballot(live && (st & STATE_PENDING)), b = __ballot(live && (st & 1));
-    if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(out2, __popcll(a));
-        if (b) atomicAdd(out2 + 1, __popcll(b));
+    bool hit = false;
+    if (slot < p.T * WTILE && slot_info(p, slot, cam, lmk)) {
+        const int st = p.state[slot];
+        if (st & STATE_PENDING) {
+            int iters = state_iters(st);
+            if (local_relin && !no_test) iters = min(iters + 1, ITERS_MAX);      // (a pending factor is not tested again: distance 0)
+            const bool damped = (st & 1) != 0 || (local_relin && iters == p.num_undamped);
+            hit = local_relin ? damped : true;
+        }
     }
+    const unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
+}
+
+// entries of the dense remainder that are not exactly zero (when none is left the handle returns to the fused sweep)
+__global__ __launch_bounds__(BLOCK) void k_count_nonzero(const double *__restrict__ x, size_t n, int *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned long long b = __ballot(i < n && x[i] != 0.0);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
 }
 
 // meas_fn / jac_fn of the reprojection factor at n free-standing points (reprojection.py:12-44): the unit the parity

@@ -94,10 +94,11 @@ int gbp_ba_iterate(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t loca
 /* the same sweep stage by stage (the reference's FactorGraph exposes all four; synchronous_iteration = robustify ->
  * relinearise -> compute_messages -> update_beliefs, gbp.py:86-92, and that fixed sequence is what gbp_ba_iterate fuses).  A
  * relinearisation decided by gbp_ba_relinearise / gbp_ba_compute_factors takes effect on the messages when they are next
- * computed; the views (gbp_ba_get_factors) show the new linearisation point at once.  gbp_ba_compute_factors with damped factors,
- * and gbp_ba_compute_messages(local_relin = 0) with pending relinearisations, need a graph created with num_undamped_iters = 0
- * (GBP_ESTATE otherwise: a damped message of a factor that has just moved its linearisation point is not in the span the
- * compact message storage covers). */
+ * computed; the views (gbp_ba_get_factors) show the new linearisation point at once.  Every call order the reference allows is
+ * allowed here: when a factor turns out to be DAMPED in the message computation that moves its linearisation point
+ * (gbp_ba_compute_factors with the damping on; gbp_ba_relinearise followed by a local_relin = 0 computation) the library switches
+ * the dense message remainder on for the handle (9 doubles per factor, allocated then) and runs its general sweep until every
+ * remainder has decayed to zero again, then returns to the fused sweep -- results as the reference's either way. */
 int gbp_ba_robustify(gbp_ba_t *h);                                      /* FactorGraph.robustify_all_factors gbp.py:82-84 */
 int gbp_ba_relinearise(gbp_ba_t *h);                                    /* FactorGraph.relinearise_factors gbp.py:64-80 */
 int gbp_ba_compute_messages(gbp_ba_t *h, int32_t local_relin);          /* FactorGraph.compute_all_messages gbp.py:46-54 (no belief changes) */

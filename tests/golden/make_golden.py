@@ -305,7 +305,57 @@ def g12(ref):
     save('G12_stagewise_vsmall', **out)
 
 
-ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12)
+def g13(ref):
+    """A factor DAMPED in the message computation that moves its linearisation point (the case a message stored in the span of its
+    Jacobian cannot hold without a dense remainder), two ways the reference allows:
+      a. compute_all_factors() while the eta damping is on (gbp.py:60-62): 12 sweeps of ba.py's schedule on fr1desk_vsmall (every
+         factor damped since sweep 8), then compute_all_factors, compute_all_messages, update_all_beliefs and three more sweeps;
+      b. relinearise_factors() followed by synchronous_iteration(local_relin=False) (gbp.py:46-54: global damping): 17 sweeps,
+         every factor allowed to relinearise again, then that pair and two ordinary sweeps.
+    Beliefs after every belief update; both messages and the state of every 5th factor after the damped message computation."""
+    from gbp import gbp_ba
+    bal = os.path.join(HERE, 'data', 'fr1desk_vsmall.txt')
+    out = {}
+
+    def snap(graph, tag, sub=None):
+        for name, arr in beliefs_of(graph).items():
+            out[f'{tag}_{name}'] = arr
+        if sub is not None:
+            fs = [graph.factors[i] for i in sub]
+            out[f'{tag}_msg_cam_eta'] = np.array([f.messages[0].eta for f in fs])
+            out[f'{tag}_msg_cam_lam'] = np.array([f.messages[0].lam for f in fs])
+            out[f'{tag}_msg_lmk_eta'] = np.array([f.messages[1].eta for f in fs])
+            out[f'{tag}_msg_lmk_lam'] = np.array([f.messages[1].lam for f in fs])
+            out[f'{tag}_linpoint'] = np.array([np.asarray(f.linpoint, dtype=np.float64) for f in fs])
+            out[f'{tag}_iters_since_relin'] = np.array([f.iters_since_relin for f in fs], dtype=np.int32)
+            out[f'{tag}_eta_damping'] = np.array([f.eta_damping for f in fs], dtype=np.float64)
+
+    graph, _ = replay(gbp_ba, bal, 12, diagnostics=False)
+    sub = np.arange(0, len(graph.factors), 5)
+    out['factor_subset'] = sub
+    out['a_n_damped'] = sum(1 for f in graph.factors if f.eta_damping > 0)
+    graph.compute_all_factors()
+    graph.compute_all_messages()
+    graph.update_all_beliefs()
+    snap(graph, 'a1', sub)
+    for k in range(3):
+        graph.synchronous_iteration(robustify=True, local_relin=True)
+    snap(graph, 'a2')
+
+    graph, _ = replay(gbp_ba, bal, 17, diagnostics=False)
+    for f in graph.factors:
+        f.iters_since_relin = 8
+    graph.relinearise_factors()
+    out['b_n_relinearised'] = sum(1 for f in graph.factors if f.iters_since_relin == 0)
+    graph.synchronous_iteration(robustify=False, local_relin=False)
+    snap(graph, 'b1', sub)
+    for k in range(2):
+        graph.synchronous_iteration(robustify=True, local_relin=True)
+    snap(graph, 'b2')
+    save('G13_damped_relinearisation_vsmall', **out)
+
+
+ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

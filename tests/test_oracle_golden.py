@@ -279,3 +279,55 @@ def test_g12_stagewise_calls_against_the_reference(oracle_mod):
         getattr(o, name)()
         check(f's{k + 1}')
     assert int(g['n_relinearised_first']) > 1000
+
+
+def g13_sequence(graph, g, replay, check):
+    """The two call sequences of fixture G13 on any object with the BAFactorGraph surface (the oracle here, the engine in
+    tests/test_stagewise_gpu.py); `check(tag)` is called where the fixture holds a snapshot."""
+    a = graph('a')
+    replay(a, 12)
+    assert int((a.relin_state()['eta_damping'] > 0).sum()) == int(g['a_n_damped']) == a.relin_state()['eta_damping'].size
+    a.compute_all_factors()
+    a.compute_all_messages()
+    a.update_all_beliefs()
+    check(a, 'a1')
+    for _ in range(3):
+        a.synchronous_iteration(robustify=True, local_relin=True)
+    check(a, 'a2')
+    b = graph('b')
+    replay(b, 17)
+    b.set_iters_since_relin(8)
+    b.relinearise_factors()
+    assert int((b.relin_state()['iters_since_relin'] == 0).sum()) == int(g['b_n_relinearised']) > 1000
+    b.synchronous_iteration(robustify=False, local_relin=False)
+    check(b, 'b1')
+    for _ in range(2):
+        b.synchronous_iteration(robustify=True, local_relin=True)
+    check(b, 'b2')
+
+
+def g13_check(g, obj, tag, belief_tol, msg_tol):
+    sub = g['factor_subset']
+    if tag + '_msg_cam_eta' in g:
+        for a, name in zip(obj.messages(), ('msg_cam_eta', 'msg_cam_lam', 'msg_lmk_eta', 'msg_lmk_lam')):
+            assert rel_err_rows(a[sub], g[f'{tag}_{name}']) < msg_tol, (tag, name)
+        f, st = obj.factors(), obj.relin_state()
+        assert np.allclose(f['linpoint'][sub], g[tag + '_linpoint'], rtol=1e-6, atol=1e-8), tag
+        assert np.array_equal(st['iters_since_relin'][sub], g[tag + '_iters_since_relin']), tag
+        assert np.array_equal(st['eta_damping'][sub], g[tag + '_eta_damping']), tag
+    assert belief_gap(obj.beliefs(), g, tag + '_') < belief_tol, tag
+
+
+def test_g13_damped_relinearisation_against_the_reference(oracle_mod):
+    """Fixture G13 (the reference itself): compute_all_factors() with the damping on, and relinearise_factors() followed by a globally
+    damped message computation -- a factor damped in the very computation that moves its linearisation point (gbp.py:46-62)."""
+    g = golden('G13_damped_relinearisation_vsmall')
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+
+    def graph(_):
+        o = oracle_mod.OracleBA.from_problem(p)
+        o.generate_priors_var(50.0)
+        o.update_all_beliefs()
+        return o
+
+    g13_sequence(graph, g, oracle_mod.replay_ba, lambda o, tag: g13_check(g, o, tag, 1e-7, 1e-6))

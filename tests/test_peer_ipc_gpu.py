@@ -92,8 +92,8 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     import json
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(GBP_BENCH_SHARE_GPU='1', GBP_XCHG_BLOCKS='16', HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_PEER_TIMEOUT_MS='8000')
-    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--lmks', '20000',
-           '--backend', 'gloo', '--exchange', 'peer', '--single-batch']
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+           '--backend', 'gloo', '--exchange', 'peer', '--single-batch']          # the headline graph: parity_check has its fixture
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -101,5 +101,10 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['exchange'] == 'peer' and out['config']['loop'] == 'in-library'
     assert len(out['per_rank']) == 2 and all(pr['ranks_reported_by_exchange'] == 2 for pr in out['per_rank'])
-    assert sum(pr['n_factors'] for pr in out['per_rank']) == 200_000
+    assert sum(pr['n_factors'] for pr in out['per_rank']) == 1_000_000
+    # the line proves itself: ten sweeps outside the timed region against the REFERENCE's own run of this graph (fixture G9b)
+    pc = out['parity_check']
+    assert pc['ok'] is True and pc['camera_beliefs_bitwise_equal_across_ranks'] is True and pc['ranks_reported_by_exchange'] == 2
+    assert pc['camera_belief_gap_vs_reference'] < 1e-6 and pc['are_trace_max_rel_err'] < 1e-6 and len(pc['are_trace']) == 11
+    assert pc['distinct_devices'] == 1 and pc['one_rank_per_device'] is False      # (two ranks share this box's one GPU, and the line says so)
     assert all(pr['sweep_ms'] > 0 and pr['reduce_and_exchange_ms'] > 0 for pr in out['per_rank'])

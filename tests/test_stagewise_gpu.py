@@ -7,26 +7,30 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA, rel_err_rows
+from conftest import golden, DATA, rel_err_rows
 from gbp_amd.balio import read_bal
 from gbp_amd.synthetic import make_synthetic
 
 pytestmark = pytest.mark.gpu
 
 
-def compare(e, o, tag, belief_tol=1e-6, msg_tol=1e-5):
+def compare(e, o, tag, belief_tol=1e-6, msg_tol=1e-5, pot_tol=1e-5):
     fe, fo = e.factors(), o.factors()
-    # (a relinearised factor's point is a belief mean, i.e. the solution of a 6x6 / 3x3 system: it inherits the belief tolerance)
-    assert np.allclose(fe['linpoint'], fo['linpoint'], rtol=1e-6, atol=1e-6), (tag, np.abs(fe['linpoint'] - fo['linpoint']).max())
-    assert rel_err_rows(fe['eta'], fo['eta']) < 1e-5 and rel_err_rows(fe['lam'], fo['lam']) < 1e-5, tag
     se, so = e.relin_state(), o.relin_state()
+    gaps = dict(linpoint=float(np.abs(fe['linpoint'] - fo['linpoint']).max()),
+                pot_eta=rel_err_rows(fe['eta'], fo['eta']), pot_lam=rel_err_rows(fe['lam'], fo['lam']),
+                msg=max(rel_err_rows(a, b) for a, b in zip(e.messages(), o.messages())),
+                belief=max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())))
+    # (a relinearised factor's point is a belief mean, i.e. the solution of a 6x6 / 3x3 system: it inherits the belief tolerance)
+    assert np.allclose(fe['linpoint'], fo['linpoint'], rtol=1e-6, atol=1e-6), (tag, gaps)
+    assert gaps['pot_eta'] < pot_tol and gaps['pot_lam'] < pot_tol, (tag, gaps)
     assert np.array_equal(se['iters_since_relin'], so['iters_since_relin']), tag
     assert np.array_equal(se['eta_damping'], so['eta_damping']), tag
     assert np.array_equal(se['robust_flag'], so['robust_flag']), tag
     assert np.allclose(se['adaptive_var'], so['adaptive_var'], rtol=1e-8), tag
-    for a, b in zip(e.messages(), o.messages()):
-        assert rel_err_rows(a, b) < msg_tol, tag
-    assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())) < belief_tol, tag
+    assert gaps['msg'] < msg_tol, (tag, gaps)
+    assert gaps['belief'] < belief_tol, (tag, gaps)
+    return gaps
 
 
 def pair(eng, oracle_mod, p, **cfg):
@@ -134,13 +138,14 @@ def test_second_relinearise_with_min_linear_zero(oracle_mod):
 
 
 def test_compute_all_factors(oracle_mod):
-    """gbp.py:60-62: every factor linearised again at the belief means, counters and damping untouched -- exact on the compact message
-    storage while no factor is damped, refused (GBP_ESTATE) once one is, and exact again on a graph that carries the dense message
-    remainder (num_undamped_iters = 0)."""
+    """gbp.py:60-62: every factor linearised again at the belief means, counters and damping untouched -- at any time, like the
+    reference: exact on the compact message storage while no factor is damped; once one is, the message computation that applies the move
+    switches the dense message remainder on (and the general sweep with it) until it has decayed to zero again, when the handle
+    returns to the fused sweep."""
     from gbp_amd import engine as eng
-    from gbp_amd._capi import GbpError
     o, e = settled_pair(eng, oracle_mod)                   # sweep 15 relinearised everybody: nobody is damped at sweep 16
     assert not (o.relin_state()['eta_damping'] > 0).any()
+    assert e.info()['cam_groups'] >= 1
     for g in (o, e):
         g.compute_all_factors()
     compare(e, o, 'after compute_all_factors')             # the views show the new linearisation at once
@@ -148,13 +153,28 @@ def test_compute_all_factors(oracle_mod):
         g.compute_all_messages()
         g.update_all_beliefs()
     compare(e, o, 'messages after compute_all_factors')
+    assert e.info()['cam_groups'] >= 1                     # nobody was damped: no remainder, still the fused sweep
     for g in (o, e):
         g.iterate(6)
     compare(e, o, 'six more sweeps')
     assert (o.relin_state()['eta_damping'] > 0).any()
-    with pytest.raises(GbpError) as ei:
-        e.compute_all_factors()
-    assert ei.value.code == -5
+    for g in (o, e):                                       # now WITH damped factors (round 3 refused this call)
+        g.compute_all_factors()
+        g.compute_all_messages()
+        g.update_all_beliefs()
+    compare(e, o, 'compute_all_factors while damped')
+    assert e.info()['cam_groups'] == 0                     # the remainder is on: general sweep
+    for g in (o, e):
+        g.iterate(2)
+    compare(e, o, 'two sweeps on the remainder', belief_tol=1e-5, msg_tol=1e-4, pot_tol=1e-3)
+    # (No parity beyond this point: a second compute_all_factors in mid-run throws the reference itself off -- ARE 50 -> 1800 -- and the
+    #  relinearisation wave that follows is chaotic: the oracle run twice with the measurements perturbed by 1e-14 differs by O(1) at that
+    #  sweep.  Fixture G13 pins what is well-posed.)  What remains to check is the life cycle: the wave zeroes every remainder (an undamped
+    #  message carries none), and the handle returns to the fused sweep at the next check.
+    e.set_iters_since_relin(8)
+    e.iterate(40)
+    assert e.info()['cam_groups'] >= 1                     # back on the fused sweep
+    assert all(np.isfinite(b).all() for b in e.beliefs())
     p = make_synthetic(n_cams=12, n_lmks=300, obs_per_lmk=5, seed=3)
     o2, e2 = pair(eng, oracle_mod, p, num_undamped_iters=0, min_linear_iters=4, eta_damping=0.4)
     for g in (o2, e2):
@@ -165,6 +185,43 @@ def test_compute_all_factors(oracle_mod):
         g.iterate(2)
     assert (o2.relin_state()['eta_damping'] > 0).all()     # damped throughout: the relinearised messages carry a dense remainder
     compare(e2, o2, 'dense remainder')
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_g13_damped_relinearisation_against_the_reference(oracle_mod, fused):
+    """Fixture G13 = the REFERENCE running compute_all_factors() with the damping on, and relinearise_factors() followed by
+    synchronous_iteration(local_relin=False): a factor damped in the message computation that moves its linearisation point.  The
+    engine allocates the dense remainder on demand; also checkpoint / restore across the switch."""
+    from gbp_amd import engine as eng
+    from test_oracle_golden import g13_sequence, g13_check
+    g = golden('G13_damped_relinearisation_vsmall')
+    p = read_bal(os.path.join(DATA, 'fr1desk_vsmall.txt'))
+    made = {}
+
+    def graph(tag):
+        e = eng.BAEngine.from_problem(p, fused=fused)
+        e.generate_priors_var(50.0)
+        e.update_all_beliefs()
+        made[tag] = e
+        return e
+
+    def check(e, tag):
+        g13_check(g, e, tag, 1e-6, 1e-5)
+        if tag in ('a1', 'b1'):
+            assert e.info()['cam_groups'] == 0             # the remainder is on: general sweep
+            blob = e.save_state()                          # a blob WITH a remainder goes into a fresh handle without one ...
+            e2 = eng.BAEngine.from_problem(p, fused=fused)
+            e2.load_state(blob)
+            for x in (e, e2):
+                x.synchronous_iteration(robustify=True, local_relin=True)
+            for u, v in zip(e.beliefs(), e2.beliefs()):
+                assert np.array_equal(u, v)                # ... and continues bit-identically
+            e.load_state(blob)                             # (back to the fixture's schedule)
+            e2.close()
+
+    g13_sequence(graph, g, oracle_mod.replay_ba, check)
+    for e in made.values():
+        e.close()
 
 
 def test_stagewise_needs_beliefs():
