@@ -115,45 +115,55 @@ class _VariableView:
         return [self._g.factors[int(f)] for f in self._g._adjacent(self._kind, self._i)]
 
 
-class _FactorView:
-    """Factor surface (gbp.py:201-249) of one reprojection factor (reference factor order)."""
-
-    def __init__(self, graph, f):
-        self._g, self.factorID = graph, f
-        self.args = (graph._K,)                          # vis/ba_vis.py:115 reads K from factors[0].args[0]
-        self.loss = graph._configs.get('loss')
-        self.mahalanobis_threshold = graph._configs.get('Nstds')
-        self.gauss_noise_var = float(graph._configs['gauss_noise_std']) ** 2
-        self.dofs_conditional_vars = 9
+class _FactorViewBase(int):
+    """Factor surface (gbp.py:201-249) of one reprojection factor (reference factor order).  A view IS its factor id (an int with no
+    state of its own: everything lives in the graph), and `iters_since_relin` -- the one attribute ba.py touches on EVERY factor in
+    EVERY iteration (ba.py:91-93 writes, :96-99 reads) -- is a property whose getter and setter are the C-level `list.__getitem__` /
+    `list.__setitem__` of the graph's host mirror: no Python frame per factor.  The class is specialised per graph (_factor_view_class)."""
+    __slots__ = ()
+    _g = None
+    dofs_conditional_vars = 9
 
     @property
-    def iters_since_relin(self):
-        return int(self._g._relin()['iters_since_relin'][self.factorID])
+    def factorID(self):
+        return int(self)
 
-    @iters_since_relin.setter
-    def iters_since_relin(self, v):
-        self._g._write_iters(self.factorID, int(v))
+    @property
+    def args(self):
+        return (self._g._K,)                             # vis/ba_vis.py:115 reads K from factors[0].args[0]
+
+    @property
+    def loss(self):
+        return self._g._configs.get('loss')
+
+    @property
+    def mahalanobis_threshold(self):
+        return self._g._configs.get('Nstds')
+
+    @property
+    def gauss_noise_var(self):
+        return float(self._g._configs['gauss_noise_std']) ** 2
 
     @property
     def eta_damping(self):
-        return float(self._g._relin()['eta_damping'][self.factorID])
+        return float(self._g._relin()['eta_damping'][self])
 
     @property
     def adaptive_gauss_noise_var(self):
-        return float(self._g._relin()['adaptive_var'][self.factorID])
+        return float(self._g._relin()['adaptive_var'][self])
 
     @property
     def robust_flag(self):
-        return bool(self._g._relin()['robust_flag'][self.factorID])
+        return bool(self._g._relin()['robust_flag'][self])
 
     @property
     def adj_vIDs(self):
-        c, l = self._g._cam_of[self.factorID], self._g._lmk_of[self.factorID]
+        c, l = self._g._cam_of[self], self._g._lmk_of[self]
         return [int(c), int(self._g._C + l)]
 
     @property
     def adj_var_nodes(self):
-        return [self._g.cam_nodes[int(self._g._cam_of[self.factorID])], self._g.lmk_nodes[int(self._g._lmk_of[self.factorID])]]
+        return [self._g.cam_nodes[int(self._g._cam_of[self])], self._g.lmk_nodes[int(self._g._lmk_of[self])]]
 
     @property
     def adj_beliefs(self):
@@ -161,20 +171,20 @@ class _FactorView:
 
     @property
     def measurement(self):
-        return self._g._lin(self.factorID)['z']
+        return self._g._lin(int(self))['z']
 
     @property
     def linpoint(self):
-        return self._g._lin(self.factorID)['linpoint']
+        return self._g._lin(int(self))['linpoint']
 
     @property
     def factor(self):
-        d = self._g._engine.factors(self.factorID, 1)
+        d = self._g._engine.factors(int(self), 1)
         return NdimGaussian(9, d['eta'][0], d['lam'][0])
 
     @property
     def messages(self):
-        ce, cl, le, ll = self._g._engine.messages(self.factorID, 1)
+        ce, cl, le, ll = self._g._engine.messages(int(self), 1)
         return [NdimGaussian(6, ce[0], cl[0]), NdimGaussian(3, le[0], ll[0])]
 
     def compute_residual(self):
@@ -184,6 +194,46 @@ class _FactorView:
 
     def reprojection_err(self):
         return float(np.linalg.norm(self.compute_residual()))
+
+
+def _factor_view_class(graph, mirror):
+    return type('_FactorView', (_FactorViewBase,), dict(__slots__=(), _g=graph, iters_since_relin=property(mirror.__getitem__, mirror.__setitem__)))
+
+
+class _FactorSeq:
+    """graph.factors: F stateless views over one host mirror.  Iterating (ba.py:92, :98) refreshes the mirror once -- 4 bytes per factor from
+    the device -- and then walks a list; whatever the loop wrote into `iters_since_relin` is found by comparing the mirror with the
+    device's values before the next device call (BAFactorGraph._flush)."""
+
+    def __init__(self, graph, n):
+        self._g, self._n = graph, n
+        self._mirror = [0] * n
+        self._cls = _factor_view_class(graph, self._mirror)
+        self._views = None
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        self._g._refresh_iters()
+        self._g._factors_touched = True
+        return self._cls(i)
+
+    def __iter__(self):
+        self._g._refresh_iters()
+        if self._views is None:
+            self._views = list(map(self._cls, range(self._n)))
+        self._g._factors_touched = True
+        return iter(self._views)
+
+    def __add__(self, other):
+        return list(self) + list(other)
 
 
 class BAFactorGraph:
@@ -207,17 +257,27 @@ class BAFactorGraph:
         self.min_linear_iters = configs['min_linear_iters']
         self.cam_nodes = _Lazy(self._C, lambda i: _VariableView(self, 0, i))
         self.lmk_nodes = _Lazy(self._L, lambda i: _VariableView(self, 1, i))
-        self.factors = _Lazy(self._F, lambda f: _FactorView(self, f))
+        self.factors = _FactorSeq(self, self._F)
         self.var_nodes = _Concat(self.cam_nodes, self.lmk_nodes)
         self.n_var_nodes, self.n_factor_nodes, self.n_edges = self._C + self._L, self._F, 2 * self._F
-        self._cache, self._iters_host, self._iters_dirty = {}, None, False
+        self._cache = {}
+        self._iters_dev, self._iters_fresh = None, False  # iters_since_relin as last read from the device; is the factors' mirror current?
+        self._factors_touched = False                     # has a view been handed out since the mirror was last compared with the device?
         self._priors_host = None                          # priors written from Python, waiting to go to the device
         self._adj = None
 
     # ---- host mirrors ------------------------------------------------------------------------------------------
     def _invalidate(self):
         self._cache.clear()
-        self._iters_host = None
+        self._iters_fresh = False
+
+    def _refresh_iters(self):
+        """graph.factors' mirror of iters_since_relin: one 4 F-byte read per device state, shared by every view"""
+        if not self._iters_fresh:
+            self._flush()                                      # (writes of an earlier loop go to the device first)
+            self._iters_dev = self._engine.iters_since_relin()
+            self.factors._mirror[:] = self._iters_dev.tolist()
+            self._iters_fresh = True
 
     def _cached(self, key, fn):
         if key not in self._cache:
@@ -255,29 +315,24 @@ class BAFactorGraph:
         return self._cached('cov', self._engine.covariances)
 
     def _relin(self):
-        st = self._cached('relin', self._engine.relin_state)
-        if self._iters_host is not None:
-            st = dict(st, iters_since_relin=self._iters_host)
-        return st
-
-    def _write_iters(self, f, v):
-        if self._iters_host is None:
-            self._iters_host = self._engine.relin_state()['iters_since_relin'].copy()
-        self._iters_host[f] = v
-        self._iters_dirty = True
+        self._flush()
+        return self._cached('relin', self._engine.relin_state)
 
     def _flush(self):
         if self._priors_host is not None:
             self._engine.set_priors(*self._priors_host)
             self._priors_host = None
             self._cache.pop('pri', None)
-        if self._iters_dirty:
-            it = self._iters_host
-            if np.all(it == it[0]):
-                self._engine.set_iters_since_relin(int(it[0]))      # ba.py:91-93 writes the same value everywhere
-            else:
-                self._engine.set_iters_since_relin(it)
-            self._iters_dirty = False
+        if self._iters_fresh and self._factors_touched:        # a loop over graph.factors may have written iters_since_relin (ba.py:91-93)
+            self._factors_touched = False
+            it = np.array(self.factors._mirror, dtype=np.int64)
+            if not np.array_equal(it, self._iters_dev):
+                if np.all(it == it[0]):
+                    self._engine.set_iters_since_relin(int(it[0]))      # ba.py:91-93 writes the same value everywhere
+                else:
+                    self._engine.set_iters_since_relin(it.astype(np.int32))
+                self._iters_dev = it.astype(np.int32)
+                self._cache.pop('relin', None)
 
     def _adjacent(self, kind, i):
         if self._adj is None:
@@ -396,7 +451,7 @@ class BAFactorGraph:
 
 
 # the reference's class names, kept importable
-ReprojectionFactor = _FactorView
+ReprojectionFactor = _FactorViewBase
 FrameVariableNode = _VariableView
 LandmarkVariableNode = _VariableView
 

@@ -82,6 +82,7 @@ struct gbp_ba {
     double *d_tmp = nullptr; size_t tmp_bytes = 0;
     std::vector<void *> allocs;
     bool has_beliefs = false;
+    int n_cus = 0;
     bool pending_possible = false;               // a stage-wise relinearise / compute_factors has run since the messages were last computed
     // dense message remainder allocated on demand (a damped factor that moves its linearisation point: enable_remainder)
     double *xtra_buf = nullptr;                  // the allocation behind p.xtra when it was made after create
@@ -362,7 +363,16 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         h->p.reverse_walk = no_rev_g ? 0 : (int)(h->gen_parity & 1u);
         h->gen_parity ^= 1u;
         CHK(ensure_staging(h));
-        CHK(launch_factor_stage(h, robustify, local_relin));
+        if (h->p.xtra || getenv("GBP_TILE_KERNEL")) {       // the dense remainder rides in k_factor_tile (one wave per tile)
+            h->dominant = "k_factor_tile";
+            CHK(launch_factor_stage(h, robustify, local_relin));
+        } else {                                             // the persistent loop, staging instead of a camera table
+            h->dominant = "k_sweep_staged";
+            CHK(time_begin(h));
+            const int rc = staged_launch(h->p, robustify, local_relin, h->n_cus, h->p.reverse_walk, h->stream, nullptr);
+            CHK(time_end(h));
+            if (rc != 0) return fail(GBP_EHIP, "general sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
         if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
         if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial, finish);
         HIPCHK(hipGetLastError());
@@ -641,7 +651,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     bool general_sweep = false;
     {
         const int n_wg = std::max(1, std::min(T, n_cus));
-        const int cgmax = fused_max_cams() + (MAX_CAM_GROUPS - 1) * pass_max_cams();
+        const int cgmax = fused_max_cams();
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
         const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
@@ -737,6 +747,7 @@ static int create_impl(gbp_ba *h, const gbp_ba_desc_t *d)
         return fail(GBP_EINVAL, "num_undamped_iters / min_linear_iters above %d are not supported (iters_since_relin saturates there)", ITERS_MAX);
     if (C >= (1 << (32 - META_LMK_BITS))) return fail(GBP_EINVAL, "more than %d cameras are not supported", (1 << (32 - META_LMK_BITS)) - 1);
 
+    h->n_cus = n_cus;
     std::vector<void *> scratch;                             // device buffers only the build needs
     const int rc = build_graph(h, d, scratch, n_cus);
     for (void *q : scratch) (void)hipFreeAsync(q, h->stream);
@@ -1970,7 +1981,7 @@ int gbp_ba_fused_max_cams(void)
 
 int gbp_ba_grouped_max_cams(void)
 {
-    return fused_max_cams() + (MAX_CAM_GROUPS - 1) * pass_max_cams();
+    return fused_max_cams();                                 // (no second camera group any more: the general sweep takes over above it)
 }
 
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks)

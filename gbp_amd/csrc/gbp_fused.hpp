@@ -135,29 +135,50 @@ GBP_DEV void st1(double *__restrict__ base, unsigned byte_off, double x) { *rein
 struct TileStreams {
     double2 a[6], m[5];
     unsigned meta;
-    int st;
+    int st, cpos;
 };
+template <bool STAGED>
 GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s)
 {
+    if (STAGED) s.cpos = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.cpos + (size_t)t * WTILE) + (unsigned)lane * 4u);
     const double *lin_t = p.lin + (size_t)t * (LIN_ROWS * WTILE);
     const double *msg_t = p.msg + (size_t)t * (MSG_ROWS * WTILE);
     const unsigned lo = (unsigned)lane * 16u;             // byte offset of this lane's 16 bytes inside a row pair (1 KB per pair)
     s.meta = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.meta + (size_t)t * WTILE) + (unsigned)lane * 4u);
     s.st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u);
+    // The general sweep streams PAST the memory-side cache (nontemporal loads), so that the 256 MiB of it keep the staged rows for
+    // k_cam_partial_staged: 126 against 132 us per sweep at 1M factors (profiles/r04_general_sweep.json).  The fused sweep does not:
+    // its whole working set fits that cache, and bypassing it cost +12...18 us (round 3).
+    if (STAGED) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { typedef double v2d __attribute__((ext_vector_type(2))); const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lin_t) + 1024u * k + lo)); s.a[k] = make_double2(v.x, v.y); }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { typedef double v2d __attribute__((ext_vector_type(2))); const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(msg_t) + 1024u * k + lo)); s.m[k] = make_double2(v.x, v.y); }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) s.a[k] = ld2(lin_t, 1024u * k + lo);
 #pragma unroll
     for (int k = 0; k < 5; ++k) s.m[k] = ld2(msg_t, 1024u * k + lo);
 }
 
-template <int LOSS, int NWAVES>
+// STAGED = the general sweep (any number of cameras): instead of adding its camera messages into the workgroup's LDS table a tile
+// writes what rebuilds them (x0 9 | q_C 2 | W 3 in one whole 128-byte line per factor) to cstage[cpos[slot]], i.e. in the camera's own
+// adj_factors order, and k_cam_partial_staged reads one contiguous run per camera.  No table, no ordered section; everything else --
+// the persistent loop, the late landmark beliefs, the addressing -- is shared with the fused sweep.  (Rounds 1-3 ran the general sweep
+// as one wave per tile, k_factor_tile: 107 us at 1M factors; that kernel now serves the stage-wise calls and the dense remainder.)
+constexpr int STAGED_WAVE_DOUBLES = WAVE_LDS_DOUBLES + WTILE * CSTAGE_PLAIN + WTILE / 2;      // messages | rows | cpos
+template <int LOSS, int NWAVES, bool STAGED = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *acc = smem;                                              // [C][27]
     const int acc_even = (a.acc_doubles + 1) & ~1, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *wl = smem + acc_even + wave * WAVE_LDS_DOUBLES;
-    int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * WAVE_LDS_DOUBLES);   // {next, done}
+    constexpr int PER_WAVE = STAGED ? STAGED_WAVE_DOUBLES : WAVE_LDS_DOUBLES;
+    double *wl = smem + acc_even + wave * PER_WAVE;
+    double *wr = wl + WAVE_LDS_DOUBLES;                              // STAGED: [64][16] rows on their way to cstage
+    int *wpos = reinterpret_cast<int *>(wr + WTILE * CSTAGE_PLAIN);  // STAGED: their row numbers
+    int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * PER_WAVE);   // {next, done}
     const int tid = threadIdx.x, lane = tid & 63;
     clk_begin(a.clk);
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
@@ -204,7 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        issue_streams(p, t, lane, S);
+        issue_streams<STAGED>(p, t, lane, S);
         const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
         const unsigned meta = S.meta;
@@ -294,6 +315,24 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             if (LOSS != 0) st1(lin_w, 5120u + lo + 8u, avar);
         }
         lmk_prefetch(p, lane, t, l0, nl, pre);             // priors | slot ranges for this tile's belief phase, one iteration from now
+        if (STAGED) {
+            // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
+            // transposed, eight whole 128-byte lines go out per instruction, 16 bytes per lane
+            if (active) {
+                double2 *row = reinterpret_cast<double2 *>(wr + lane * CSTAGE_PLAIN);
+                row[0] = make_double2(x0[0], x0[1]); row[1] = make_double2(x0[2], x0[3]); row[2] = make_double2(x0[4], x0[5]);
+                row[3] = make_double2(x0[6], x0[7]); row[4] = make_double2(x0[8], qC[0]); row[5] = make_double2(qC[1], WC[0]);
+                row[6] = make_double2(WC[1], WC[2]); row[7] = make_double2(0.0, 0.0);
+                wpos[lane] = S.cpos;
+            }
+            wave_lds_sync();
+            const int g8 = lane >> 3, k2 = lane & 7;
+            for (int f = g8; f < nf; f += 8)
+                reinterpret_cast<double2 *>(p.cstage + (size_t)wpos[f] * CSTAGE_PLAIN)[k2] = reinterpret_cast<const double2 *>(wr + f * CSTAGE_PLAIN)[k2];
+            wave_lds_sync();
+            pend = true; q_l0 = l0; q_nl = nl;
+            continue;
+        }
         wave_lds_sync();
         GBP_PH_NOWAIT(7);                                  // stores issued
         // camera accumulation strictly in tile order
@@ -301,7 +340,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
-        const int cloc = cam - a.cam_base;                 // (cameras of later groups are added up by k_cam_pass)
+        const int cloc = cam - a.cam_base;
         const bool mine = active && (unsigned)cloc < (unsigned)a.cam_count;
         for (int r = 0; r <= ((a.dbg & 32) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
             if (mine && rank == r && !(a.dbg & 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
@@ -317,6 +356,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         pend = true; q_l0 = l0; q_nl = nl;
     }
     if (lane == 0) relin_add(p, n_relin);
+    if (STAGED) return;
     GBP_PH_NOWAIT(9);
     __syncthreads();
     GBP_PH_NOWAIT(10);                                     // waiting for the other waves of the workgroup
@@ -328,74 +368,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     }
     GBP_PH(11);                                            // table write-out
     GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
-}
-
-// More cameras than one LDS table holds (C > 516): the sweep above adds up the messages to the first group of cameras; one
-// launch of this kernel per further group adds up the rest.  The message to the camera is rebuilt from what the sweep has just
-// stored -- eta = Jc^T q_C, Lambda = Jc^T W Jc with Jc at the factor's linearisation point (14 doubles per factor) -- instead
-// of travelling through a camera-major staging buffer (27 doubles written + read, scattered: the general sweep).  Same tile
-// walk, same in-order accumulation by (workgroup, tile, rank): the sums are bitwise those a single table would give.
-template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_cam_pass(Params p, FusedArgs a, const int4 *__restrict__ tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *acc = smem;
-    int *ctl = reinterpret_cast<int *>(smem + ((a.acc_doubles + 1) & ~1));
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
-    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
-    __syncthreads();
-    const int tb = (int)((long long)blockIdx.x * p.T / gridDim.x), ntl = (int)((long long)(blockIdx.x + 1) * p.T / gridDim.x) - tb;
-    for (;;) {
-        int ti = 0;
-        if (lane == 0) ti = atomicAdd(&ctl[0], 1);
-        ti = __builtin_amdgcn_readfirstlane(ti);
-        if (ti >= ntl) break;
-        const int t = tb + (a.reverse ? ntl - 1 - ti : ti);
-        const int4 td = tiles[t];
-        const int slot = t * WTILE + lane;
-        const unsigned meta = p.meta[slot];
-        const int st = p.state[slot];
-        const int cloc = (int)(meta >> META_LMK_BITS) - a.cam_base;
-        const bool mine = lane < td.z && (unsigned)cloc < (unsigned)a.cam_count;
-        double x0[9], qC[2], WC[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) qC[k] = p.msg[msg_at(slot, ROW_QC + k)];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
-        double eC[6], MC[21];
-        if (mine) {
-            double Jc[2][6], Jl[2][3], h[2];
-            linearise(x0, p.K, Jc, Jl, h);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) eC[k] = Jc[0][k] * qC[0] + Jc[1][k] * qC[1];
-#pragma unroll
-            for (int k = 0; k < 21; ++k) MC[k] = 0.0;
-            rank2_update<6>(MC, Jc[0], Jc[1], WC, 1.0);
-        }
-        while (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ti) __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
-        const int rank = state_rank(st);
-        for (int r = 0; r <= td.w; ++r) {
-            if (mine && rank == r) {
-                double *dst = acc + cloc * 27;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) unsafeAtomicAdd(dst + k, eC[k]);
-#pragma unroll
-                for (int k = 0; k < 21; ++k) unsafeAtomicAdd(dst + 6 + k, MC[k]);
-            }
-        }
-        wave_lds_sync();
-        if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    for (int i = tid; i < (a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
-        const int c = i / (TROW / 2), k = 2 * (i - c * (TROW / 2));
-        const double2 v = make_double2(acc[c * 27 + k], k + 1 < 27 ? acc[c * 27 + k + 1] : 0.0);
-        *reinterpret_cast<double2 *>(a.block_partials + ((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * TROW + k) = v;
-    }
 }
 
 // One workgroup per camera: partial[c] = sum over the per-workgroup tables in a fixed order (bitwise reproducible).
@@ -499,13 +471,12 @@ __global__ __launch_bounds__(RED_THREADS, 8) void k_cam_reduce_xchg(Params p, co
 
 // ------------------------------------------------------------------------------------ host --
 
-constexpr int MAX_CAM_GROUPS = 2;                   // a third group already costs more than the staged general sweep (measured, C = 1500)
-constexpr int PASS_WAVES = 16;                      // k_cam_pass keeps little state per lane: four waves per SIMD
+// (Rounds 2-3 added the messages to a second group of up to 758 cameras in an extra pass over the stored messages, k_cam_pass: 138.7 us
+//  per sweep at C = 1000.  The general sweep's persistent STAGED form does the same graph in 127 us and has no camera limit: removed.)
 
 struct FusedPlan {
     bool enabled = false;
-    int n_groups = 0, group_cams = 0, pass_cams = 0; // the sweep adds up the first group_cams cameras, every k_cam_pass launch pass_cams more
-    size_t pass_shmem = 0;
+    int n_groups = 0, group_cams = 0;                // (one camera group: the whole table in LDS)
     int n_blocks = 0, n_big = 0;
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     size_t shmem = 0;
@@ -545,9 +516,6 @@ inline size_t fused_shmem(int C)
     return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * WAVE_LDS_DOUBLES + 1);
 }
 
-// most cameras one k_cam_pass launch adds up: its table and two control words are all it keeps in the LDS
-inline int pass_max_cams() { return (LDS_BYTES - 16) / (27 * (int)sizeof(double)); }
-
 // most cameras whose table + the per-wave scratch fit the LDS (the plan falls back to the general sweep above it)
 inline int fused_max_cams()
 {
@@ -560,15 +528,13 @@ inline int fused_max_cams()
 inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
 {
     if (p.F == 0 || p.C == 0 || p.T == 0) return 0;
-    // the sweep's own table shares the LDS with the waves' scratch (516 cameras); k_cam_pass has the LDS to itself (758)
-    const int cmax = fused_max_cams(), pmax = pass_max_cams();
-    if (p.C > cmax + (MAX_CAM_GROUPS - 1) * pmax) return 0;                            // general sweep instead
-    pl.group_cams = std::min(p.C, cmax);
-    pl.n_groups = 1 + (p.C - pl.group_cams + pmax - 1) / pmax;
-    pl.pass_cams = pl.n_groups > 1 ? (p.C - pl.group_cams + pl.n_groups - 2) / (pl.n_groups - 1) : 0;
+    // the sweep's table shares the LDS with the waves' scratch: more cameras than fit run the general sweep (STAGED form of the same loop)
+    const int cmax = fused_max_cams();
+    if (p.C > cmax) return 0;
+    pl.group_cams = p.C;
+    pl.n_groups = 1;
     const int acc_doubles = pl.group_cams * 27;
     const size_t shmem = fused_shmem(pl.group_cams);
-    pl.pass_shmem = sizeof(double) * (size_t)(((pl.pass_cams * 27 + 1) & ~1) + 2);
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
     double *d_bp = nullptr;                                 // (workgroup b walks tiles [b T / n_blocks, (b + 1) T / n_blocks): computed in the kernels)
@@ -586,8 +552,6 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
                             (int)shmem) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
-    if (pl.n_groups > 1 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cam_pass<PASS_WAVES>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pass_shmem) != hipSuccess) return -1;
 #undef GBP_SET_SHMEM
     pl.enabled = true;
     return 0;
@@ -610,13 +574,6 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
-    for (int g = 1; g < pl.n_groups; ++g) {                 // the messages to the cameras of the further groups (C > 516)
-        FusedArgs ag = pl.args;
-        ag.cam_base = pl.group_cams + (g - 1) * pl.pass_cams;
-        ag.cam_count = std::min(p.C - ag.cam_base, pl.pass_cams);
-        ag.acc_doubles = ag.cam_count * 27;
-        hipLaunchKernelGGL((k_cam_pass<PASS_WAVES>), grid, dim3(PASS_WAVES * 64), pl.pass_shmem, stream, p, ag, p.tiles);
-    }
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
     const size_t red_shmem = 0;                             // (static LDS)
     PeerOut po{};
@@ -639,6 +596,32 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po, clk ? clk + 2 : nullptr);
+    return (int)hipGetLastError();
+}
+
+// the general sweep's factor kernel: the persistent loop in its STAGED form (no table: any number of cameras)
+inline int staged_launch(const Params &p0, int robustify, int local_relin, int n_cus, int reverse, hipStream_t stream, unsigned long long *clk)
+{
+    Params p = p0;
+    p.robustify = robustify; p.local_relin = local_relin;
+    FusedArgs a{};
+    a.reverse = reverse; a.clk = clk;
+    const int n_blocks = std::max(1, std::min(p.T, n_cus));
+    const size_t shmem = sizeof(double) * ((size_t)WAT_WAVES * STAGED_WAVE_DOUBLES + 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_wat<0, WAT_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_wat<1, WAT_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_wat<2, WAT_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+            return (int)hipErrorUnknown;
+        attr_set = true;
+    }
+    const dim3 grid(n_blocks), block(WAT_WAVES * 64);
+    switch (p.loss) {
+    case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, true>), grid, block, shmem, stream, p, a, p.tiles); break;
+    case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, true>), grid, block, shmem, stream, p, a, p.tiles); break;
+    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, true>), grid, block, shmem, stream, p, a, p.tiles); break;
+    }
     return (int)hipGetLastError();
 }
 

@@ -224,11 +224,11 @@ int gbp_ba_get_sweep_clocks(gbp_ba_t *h, double *us6, int32_t cap_sweeps, int32_
 enum { GBP_COMM_NONE = 0, GBP_COMM_CALLBACK = 1, GBP_COMM_RCCL = 2, GBP_COMM_PEER = 3 };
 int gbp_ba_comm_info(gbp_ba_t *h, int32_t *kind, int32_t *rank, int32_t *n_ranks);
 int gbp_ba_get_kernel_times(gbp_ba_t *h, double *ms, int32_t cap, int32_t *n_launches);   /* each bracketed launch, in order; call BEFORE get_kernel_timing (which resets) */
-int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);   /* fused_path: 0 = general sweep, g >= 1 = fused sweep with g camera groups (g - 1 extra k_cam_pass launches) */
+int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);   /* fused_path: 0 = general sweep (camera-major staging, any number of cameras), 1 = fused sweep (camera table in LDS) */
 int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols);   /* debug builds with -DGBP_PHASE_TIMING only (tools/phase_profile.py): per-wave time per phase of the last fused sweep */
 int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots);   /* debug: slots whose (camera, landmark) do not match the reference factor they hold (0 = sound) */
-int gbp_ba_grouped_max_cams(void);  /* most cameras of the fused sweep with its extra camera-group pass (516 + 758); above it the general sweep runs */
-int gbp_ba_fused_max_cams(void);    /* most cameras of ONE camera group of the fused sweep (camera table + wave scratch in 160 KB of LDS); one further group of up to 758 cameras is added up by k_cam_pass (gbp_ba_grouped_max_cams), then the general sweep */
+int gbp_ba_grouped_max_cams(void);  /* = gbp_ba_fused_max_cams() since round 4 (the extra camera-group pass is gone); kept for ABI stability */
+int gbp_ba_fused_max_cams(void);    /* most cameras of the fused sweep (camera table + wave scratch in 160 KB of LDS); above it the general sweep runs */
 
 #ifdef __cplusplus
 }

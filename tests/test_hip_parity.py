@@ -466,18 +466,18 @@ def test_full_size_properties_1m_factors(eng_mod):
 
 
 def test_many_cameras_fall_back_to_the_general_sweep(eng_mod, oracle_mod):
-    """C = 700 cameras: the camera table of the fused sweep (C x 27 doubles) no longer fits the LDS, so the engine splits
-    the cameras into two groups (fused sweep + one k_cam_pass launch); forced to the tile-based general sweep
-    (k_factor_tile + camera-major staging) it must give the same results, incl. one landmark larger than a tile (its belief
-    comes from k_lmk_belief_list)."""
+    """C = 700 and 3000 cameras: the camera table of the fused sweep (C x 27 doubles) no longer fits the LDS, so the engine runs the
+    general sweep (the persistent loop with camera-major staging + k_cam_partial_staged), whatever `fused` asks for; incl. one
+    landmark larger than a tile (its belief comes from k_lmk_belief_list)."""
     big = make_synthetic(n_cams=700, n_lmks=1, obs_per_lmk=90, seed=8)
     q = make_synthetic(n_cams=700, n_lmks=900, obs_per_lmk=6, seed=9)
     prob = BAProblem(K=q.K, cam_means=q.cam_means, lmk_means=np.concatenate([big.lmk_means[:1], q.lmk_means]),
                      meas=np.concatenate([big.meas, q.meas]), cam_idx=np.concatenate([big.cam_idx, q.cam_idx]),
                      lmk_idx=np.concatenate([big.lmk_idx, q.lmk_idx + 1]).astype(np.int32))
-    for fused, groups in ((True, 2), (False, 0)):
-        gap, o, e = oracle_vs_engine(eng_mod, oracle_mod, prob, 20, fused)
-        assert e.info()['cam_groups'] == groups
+    big3 = make_synthetic(n_cams=3000, n_lmks=4000, obs_per_lmk=12, seed=10)      # 16 factors per camera
+    for pr, fused in ((prob, True), (prob, False), (big3, True)):
+        gap, o, e = oracle_vs_engine(eng_mod, oracle_mod, pr, 20, fused)
+        assert e.info()['cam_groups'] == 0
         assert gap < BELIEF_TOL, gap
         assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
         for a, b in zip(e.messages(), o.messages()):

@@ -174,7 +174,7 @@ def test_sharded_engine_synthetic_two_ranks(oracle_mod):
 
 
 def test_sharded_engine_with_camera_groups_and_oversized_landmarks(oracle_mod):
-    """700 cameras (two camera groups: fused sweep + k_cam_pass) and landmarks seen by more than 64 cameras (chunk tiles whose
+    """700 cameras (more than the fused sweep's LDS table holds: the general sweep) and landmarks seen by more than 64 cameras (chunk tiles whose
     beliefs run on the side stream beside the exchange) through the in-library loop at world size 2."""
     from gbp_amd.engine import BAEngine
     from gbp_amd.synthetic import BAProblem
@@ -187,7 +187,7 @@ def test_sharded_engine_with_camera_groups_and_oversized_landmarks(oracle_mod):
     meas = np.concatenate([big.meas[big.lmk_idx < 2], q.meas, big.meas[big.lmk_idx == 2]])
     p = BAProblem(K=q.K, cam_means=q.cam_means, lmk_means=lm, meas=meas, cam_idx=cidx.astype(np.int32), lmk_idx=lidx.astype(np.int32))
     ref = BAEngine.from_problem(p)
-    assert ref.info()['cam_groups'] == 2
+    assert ref.info()['cam_groups'] == 0
     ref.generate_priors_var(50.0); ref.update_all_beliefs()
     ares, energies = oracle_mod.replay_ba(ref, 10, diagnostics=True)
     rce, rcl, rle, rll = ref.beliefs()
