@@ -105,7 +105,13 @@ for size, F, L, C in (('1m', 1_000_000, 100_000, 500), ('10m', 10_000_000, 1_000
             t["bench_value_it_s"] = line["value"]
         traffic[size] = t
 if traffic:
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gbp_amd', 'libgbp_hip.so')
+    usage = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', f'{tag}_kernel_resource_usage.txt')
     doc = {"round": tag, "kernel": "k_sweep_wat<0, 8> (k_sweep_fused)",
+           "library_sha256_16": hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16] if os.path.exists(lib) else None,
+           "library_note": "the binary these passes measured; bench.py reports `traffic` only when it runs this very file",
+           "kernel_resource_usage": [ln.strip() for ln in open(usage)] if os.path.exists(usage) else None,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh); FETCH_SIZE doubled "
                      "(gfx950, MI355X_MICROARCH.md 'HBM'), checked against k_cam_reduce_tree, whose read is exactly 256 x C x 28 doubles",
            "traffic_bytes_per_launch": traffic.get('1m', {}).get('traffic_bytes_per_launch'), "sizes": traffic}
