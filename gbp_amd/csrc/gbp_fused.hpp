@@ -81,6 +81,7 @@ struct FusedArgs {
     int acc_doubles;            // cameras of the group * 27
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
     int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
+    int nt;                     // which factor streams bypass the memory-side cache (issue_streams)
     int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase,
                                 // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results),
                                 // 32 only the first round of the accumulation (same-camera duplicates of a tile dropped)
@@ -137,8 +138,20 @@ struct TileStreams {
     unsigned meta;
     int st, cpos;
 };
+GBP_DEV double2 ld2_nt(const double *__restrict__ base, unsigned byte_off)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(base) + byte_off));
+    return make_double2(v.x, v.y);
+}
+
+// nt: bit 0 = the lin rows (x0 | z | variance) stream PAST the memory-side cache, bit 1 = the message rows too (nontemporal loads:
+// no allocation in the 256 MiB Infinity Cache).  The fused sweep of a graph whose whole working set fits that cache uses neither (at the
+// headline size bypassing it costs +12...18 us); a larger graph sends past it what does not fit, so that the rest STAYS resident from
+// sweep to sweep instead of everything thrashing (fused_launch picks the bits from the sizes); the general sweep sends both past it
+// so that the cache keeps the staged camera rows for k_cam_partial_staged (126 against 132 us per sweep at 1M factors).
 template <bool STAGED>
-GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s)
+GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int nt)
 {
     if (STAGED) s.cpos = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.cpos + (size_t)t * WTILE) + (unsigned)lane * 4u);
     const double *lin_t = p.lin + (size_t)t * (LIN_ROWS * WTILE);
@@ -146,20 +159,20 @@ GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s)
     const unsigned lo = (unsigned)lane * 16u;             // byte offset of this lane's 16 bytes inside a row pair (1 KB per pair)
     s.meta = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.meta + (size_t)t * WTILE) + (unsigned)lane * 4u);
     s.st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u);
-    // The general sweep streams PAST the memory-side cache (nontemporal loads), so that the 256 MiB of it keep the staged rows for
-    // k_cam_partial_staged: 126 against 132 us per sweep at 1M factors (profiles/r04_general_sweep.json).  The fused sweep does not:
-    // its whole working set fits that cache, and bypassing it cost +12...18 us (round 3).
-    if (STAGED) {
+    if (STAGED || (nt & 1)) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { typedef double v2d __attribute__((ext_vector_type(2))); const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(lin_t) + 1024u * k + lo)); s.a[k] = make_double2(v.x, v.y); }
+        for (int k = 0; k < 6; ++k) s.a[k] = ld2_nt(lin_t, 1024u * k + lo);
+    } else {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { typedef double v2d __attribute__((ext_vector_type(2))); const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(reinterpret_cast<const char *>(msg_t) + 1024u * k + lo)); s.m[k] = make_double2(v.x, v.y); }
-        return;
+        for (int k = 0; k < 6; ++k) s.a[k] = ld2(lin_t, 1024u * k + lo);
     }
+    if (STAGED || (nt & 2)) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s.a[k] = ld2(lin_t, 1024u * k + lo);
+        for (int k = 0; k < 5; ++k) s.m[k] = ld2_nt(msg_t, 1024u * k + lo);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) s.m[k] = ld2(msg_t, 1024u * k + lo);
+        for (int k = 0; k < 5; ++k) s.m[k] = ld2(msg_t, 1024u * k + lo);
+    }
 }
 
 // STAGED = the general sweep (any number of cameras): instead of adding its camera messages into the workgroup's LDS table a tile
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        issue_streams<STAGED>(p, t, lane, S);
+        issue_streams<STAGED>(p, t, lane, S, a.nt);
         const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
         const unsigned meta = S.meta;
@@ -546,7 +559,20 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 #ifdef GBP_PHASE_TIMING
     if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
 #endif
-    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, env_dbg ? atoi(env_dbg) : 0, d_phase, nullptr};
+    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, 0, env_dbg ? atoi(env_dbg) : 0, d_phase, nullptr};
+    {
+        // What a sweep touches, against the 256 MiB memory-side cache.  Everything fits: nothing bypasses it.  Beyond it the lin rows
+        // (read-only in steady sweeps, 96 B per slot) go past it, so that the message rows and the records stay resident instead of
+        // everything thrashing: 94 against 99 us per sweep at 1.2M factors, 115 against 124 at 1.5M, neutral from 2M on, and WORSE
+        // below the cache size (88 against 82 us at 1.1M; at 1M 81 against 69): profiles/r04_size_sweep.jsonl.  Bypassing the message
+        // rows as well (bit 1) never paid.
+        const double S = (double)p.T * WTILE, MiB = 1024.0 * 1024.0;
+        const double touched = S * (LIN_ROWS + MSG_ROWS) * 8 + S * 8 + (double)p.L * LREC * 8 + (double)pl.n_blocks * p.C * TROW * 8 +
+                               (double)p.C * (CAMREC + CBEL + 27) * 8;
+        int nt = touched > 256.0 * MiB ? 1 : 0;
+        if (const char *e = getenv("GBP_FUSED_NT")) nt = atoi(e);
+        pl.args.nt = nt;
+    }
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
