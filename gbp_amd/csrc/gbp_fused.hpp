@@ -397,13 +397,15 @@ constexpr int RED_G = 9;                            // ... then 9, then 1
 constexpr int RED_LDS_DOUBLES = (RED_PARTS + RED_G) * TROW + 28;
 
 // returns entry tid (< 27) of the camera's sum in threads 0..26 (0.0 elsewhere); red = RED_LDS_DOUBLES doubles of LDS.  The caller
-// synchronises the block before red is used again.
+// synchronises the block before red is used again.  NT = threads of the block: the 73 x 14 (part, pair) items are dealt out over them,
+// so the sums -- and their order -- are the same for every block size (the peer-exchange kernel runs 256-thread blocks).
+template <int NT>
 GBP_DEV double cam_reduce_sum(const double *__restrict__ src, int n_blocks, double *red, int tid)
 {
     double *red2 = red + RED_PARTS * TROW;
-    const int part = tid / RED_PAIRS, pair = tid - part * RED_PAIRS;
-    if (part < RED_PARTS) {
-        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    for (int item = tid; item < RED_PARTS * RED_PAIRS; item += NT) {
+        const int part = item / RED_PAIRS, pair = item - part * RED_PAIRS;
         double sx = 0.0, sy = 0.0;
         for (int b0 = part; b0 < n_blocks; b0 += 4 * RED_PARTS) {
             double2 v[4];
@@ -412,7 +414,7 @@ GBP_DEV double cam_reduce_sum(const double *__restrict__ src, int n_blocks, doub
 #pragma unroll
             for (int j = 0; j < 4; ++j) { sx += v[j].x; sy += v[j].y; }
         }
-        reinterpret_cast<double2 *>(red)[part * RED_PAIRS + pair] = make_double2(sx, sy);
+        reinterpret_cast<double2 *>(red)[item] = make_double2(sx, sy);
     }
     __syncthreads();
     if (tid < RED_G * TROW) {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     const int c = blockIdx.x, tid = threadIdx.x;
     clk_begin(clk);
     double *tot = sh + (RED_PARTS + RED_G) * TROW;
-    const double s = cam_reduce_sum(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);
+    const double s = cam_reduce_sum<RED_THREADS>(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);
     if (tid < 27) {
         partial[(size_t)c * 27 + tid] = s;
         tot[tid] = s + p.cprior[(size_t)c * 27 + tid];
@@ -458,20 +460,22 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
 // Sharded sweep with the peer-store exchange, everything after the sweep kernel in ONE launch: a small grid of persistent
 // workgroups first reduces and PUSHES all of its cameras (workgroup tables -> 27 sums -> row c of every rank's mailbox + tag),
 // then finishes them, one wave per camera: wait for the n_ranks tags of row c, add the parts in rank order, prior, mean | covariance.
-// Every workgroup of every rank pushes before it waits, and the grid is never larger than what is resident at once (XCHG_BLOCKS = two
-// 1024-thread workgroups per CU of an MI355X; one camera per workgroup up to 512 cameras, several beyond), so ranks cannot wait for
-// each other in a cycle (__launch_bounds__(1024, 8): 64 VGPRs so that TWO workgroups fit a CU; fused_launch caps the grid at what the
-// occupancy query admits).  Against reduce -> finish as two launches this saves a kernel boundary and the global "all rows are out"
-// hand-off; against RCCL also the collective's launch and sync.
-constexpr int XCHG_BLOCKS = 512;
-__global__ __launch_bounds__(RED_THREADS, 8) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
-                                                                 double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk)
+// Every workgroup of every rank pushes before it waits, and the grid is never larger than what is resident at once (256-thread
+// workgroups: eight per CU of an MI355X; one camera per workgroup up to 2048 cameras, several beyond; fused_launch caps the grid at
+// what the occupancy query admits), so ranks cannot wait for each other in a cycle.  (Round 3 ran 1024-thread workgroups bound to 64
+// VGPRs so that two fit a CU; the seven-lane mean | covariance solve of the finish spilled 55 of them: +4 us per sweep.)  Against
+// reduce -> finish as two launches this saves a kernel boundary and the global "all rows are out" hand-off; against RCCL also the
+// collective's launch and sync.
+constexpr int XCHG_THREADS = 256;
+constexpr int XCHG_BLOCKS = 2048;
+__global__ __launch_bounds__(XCHG_THREADS) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
+                                                                  double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk)
 {
     __shared__ __attribute__((aligned(16))) double sh[RED_LDS_DOUBLES];
     const int tid = threadIdx.x;
     clk_begin(clk);
     for (int c = blockIdx.x; c < p.C; c += gridDim.x) {
-        const double s = cam_reduce_sum(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);      // the same order as k_cam_reduce_tree: bitwise the same sums
+        const double s = cam_reduce_sum<XCHG_THREADS>(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);      // the same order as k_cam_reduce_tree: bitwise the same sums
         if (tid < 64) {
             if (tid < 27) partial[(size_t)c * 27 + tid] = s;
             peer_push_row(peer, c, s, tid);
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(RED_THREADS, 8) void k_cam_reduce_xchg(Params p, co
         __syncthreads();                                     // sh is overwritten by the next camera
     }
     const int wave = tid >> 6, lane = tid & 63;
-    for (int c = blockIdx.x + wave * gridDim.x; c < p.C; c += (RED_THREADS / 64) * gridDim.x) cam_finish_wave(p, nullptr, peer.n, 0, wait, c, lane);
+    for (int c = blockIdx.x + wave * gridDim.x; c < p.C; c += (XCHG_THREADS / 64) * gridDim.x) cam_finish_wave(p, nullptr, peer.n, 0, wait, c, lane);
 }
 
 // ------------------------------------------------------------------------------------ host --
@@ -610,14 +614,14 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
         int xb = pl.xchg_blocks;
         if (xb == 0) {
             int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_cam_reduce_xchg), RED_THREADS, red_shmem) != hipSuccess ||
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_cam_reduce_xchg), XCHG_THREADS, red_shmem) != hipSuccess ||
                 hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
                 return (int)hipErrorUnknown;
             xb = std::min(XCHG_BLOCKS, per_cu * cus);
             if (const char *e = getenv("GBP_XCHG_BLOCKS")) xb = std::max(1, std::min(xb, atoi(e)));
             pl.xchg_blocks = xb;
         }
-        hipLaunchKernelGGL(k_cam_reduce_xchg, dim3(std::min(p.C, xb)), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial,
+        hipLaunchKernelGGL(k_cam_reduce_xchg, dim3(std::min(p.C, xb)), dim3(XCHG_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial,
                            po, *merged, clk ? clk + 2 : nullptr);
         return (int)hipGetLastError();
     }
