@@ -87,6 +87,7 @@ struct gbp_ba {
     // dense message remainder allocated on demand (a damped factor that moves its linearisation point: enable_remainder)
     double *xtra_buf = nullptr;                  // the allocation behind p.xtra when it was made after create
     bool lazy_xtra = false, fused_suspended = false;
+    int cstage_cap = 0;                          // doubles per row the staging buffer was allocated for (0: not allocated yet)
     long lazy_since = 0;                         // sweeps run since the remainder was switched on (it is checked for all-zero every 16)
     bool resid_ok = false; double resid[2] = {0.0, 0.0};     // ARE / energy sums of the CURRENT state (ba.py asks for both every sweep)
     // streaming means export (viewer): device staging, two pinned host mirrors, a copy stream
@@ -294,7 +295,10 @@ static int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, siz
 // camera-major staging of the general sweep, allocated on first use (F x 27 doubles; the slot -> row map cpos is made by the build)
 static int ensure_staging(gbp_ba *h)
 {
-    if (!h->p.cstage) CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * h->p.crow));
+    if (!h->p.cstage || h->cstage_cap < h->p.crow) {
+        CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * h->p.crow));
+        h->cstage_cap = h->p.crow;
+    }
     if (!h->big_lmks.empty() && !h->d_big) {
         CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
         CHK(upload(h, h->d_big, h->big_lmks));
@@ -652,6 +656,15 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     {
         const int n_wg = std::max(1, std::min(T, n_cus));
         const int cgmax = fused_max_cams();
+        // Few factors per camera: the fused sweep writes (and its reduce reads back) one 224-byte table row per camera and WORKGROUP
+        // whatever the graph's size, the staged form one 128-byte row per FACTOR.  Below ~0.75 factors per (workgroup, camera) the
+        // staged sweep is the faster one -- 13k / 30k / 60k / 90k factors x 500 cameras: 18.6 / 20.5 / 24.2 / 29.1 against 26.3 /
+        // 28.6 / 28.9 / 30.2 us per sweep, 125k: 35.8 against 32.8 (profiles/r04_shards.json) -- e.g. a rank's share at 16 ranks and
+        // beyond.  GBP_STAGED_BELOW overrides the 0.75 (0: never).
+        double staged_below = 0.75;
+        if (const char *e = getenv("GBP_STAGED_BELOW")) staged_below = atof(e);
+        const bool sparse = (double)F < staged_below * (double)n_wg * (double)C;
+        if (sparse) h->flags |= GBP_FLAG_NO_FUSED;
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
         const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
@@ -660,7 +673,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
                           + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);
         CHK(arena_reserve(h, need));
     }
-    if (general_sweep && F > 0) CHK(dev_alloc(h, &p.cstage, Fz * p.crow));   // out of the same arena (else: on first use, ensure_staging)
+    if (general_sweep && F > 0) { CHK(dev_alloc(h, &p.cstage, Fz * p.crow)); h->cstage_cap = p.crow; }   // out of the same arena (else: on first use, ensure_staging)
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
     if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
     CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
@@ -919,7 +932,7 @@ static int enable_remainder(gbp_ba *h)
     }
     HIPCHK(hipMemsetAsync(h->xtra_buf, 0, n * sizeof(double), h->stream));
     p.xtra = h->xtra_buf;
-    if (p.crow != CSTAGE_ROW) { p.crow = CSTAGE_ROW; p.cstage = nullptr; }      // staged rows carry the remainder too: a wider buffer (ensure_staging)
+    p.crow = CSTAGE_ROW;                                     // staged rows carry the remainder too: ensure_staging widens the buffer if need be
     h->lazy_xtra = true; h->lazy_since = 0;
     h->fused_suspended = h->fused.enabled;
     h->fused.enabled = false;
@@ -954,6 +967,7 @@ static int remainder_release(gbp_ba *h)
     HIPCHK(hipStreamSynchronize(h->stream));
     if (c) return GBP_OK;
     h->p.xtra = nullptr;                                     // (the buffer stays for the next time)
+    h->p.crow = CSTAGE_PLAIN;                                // the staged rows are 16 doubles wide again (the buffer keeps its size)
     h->lazy_xtra = false;
     if (h->fused_suspended) { h->fused.enabled = true; h->dominant = "k_sweep_fused"; }
     return GBP_OK;
@@ -1763,6 +1777,7 @@ static int remainder_drop(gbp_ba *h)
 {
     if (!h->lazy_xtra || !h->p.xtra) return GBP_OK;
     h->p.xtra = nullptr;
+    h->p.crow = CSTAGE_PLAIN;
     h->lazy_xtra = false;
     if (h->fused_suspended) { h->fused.enabled = true; h->dominant = "k_sweep_fused"; }
     return GBP_OK;

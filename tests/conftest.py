@@ -8,6 +8,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# The engine picks the staged (general) sweep on its own for graphs with few factors per camera (gbp_capi.hip: GBP_STAGED_BELOW); the
+# tests name the sweep they mean (fused=True / False), so the automatic choice is off here and has a test of its own
+# (tests/test_edge_shapes_gpu.py::test_sparse_graphs_take_the_staged_sweep).
+os.environ.setdefault('GBP_STAGED_BELOW', '0')
+
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 DATA = os.path.join(GOLDEN, 'data')
 

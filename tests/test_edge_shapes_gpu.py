@@ -40,6 +40,18 @@ def test_camera_count_at_the_lds_boundary(oracle_mod):
             assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
 
 
+def test_sparse_graphs_take_the_staged_sweep(oracle_mod, monkeypatch):
+    """Few factors per (workgroup, camera): the engine runs the staged sweep although the camera table would fit the LDS (one 128-byte row
+    per factor instead of one 224-byte table row per camera and workgroup); a dense graph keeps the fused sweep."""
+    monkeypatch.delenv('GBP_STAGED_BELOW', raising=False)
+    sparse = make_synthetic(n_cams=400, n_lmks=1500, obs_per_lmk=6, seed=4)          # 9 000 factors, 150 tiles x 400 cameras
+    gap, o, e = run_pair(oracle_mod, sparse, n_sweeps=12)
+    assert e.info()['cam_groups'] == 0 and gap < BELIEF_TOL, (e.info(), gap)
+    dense = make_synthetic(n_cams=12, n_lmks=1500, obs_per_lmk=6, seed=4)
+    gap, o, e = run_pair(oracle_mod, dense, n_sweeps=12)
+    assert e.info()['cam_groups'] == 1 and gap < BELIEF_TOL, (e.info(), gap)
+
+
 def with_landmarks(p, degrees, seed=5):
     """p plus one landmark per entry of `degrees`, seen by that many cameras (points near the origin are in front of
     and inside the image of every camera of the generator's shell)."""

@@ -220,6 +220,15 @@ def test_g13_damped_relinearisation_against_the_reference(oracle_mod, fused):
             e2.close()
 
     g13_sequence(graph, g, oracle_mod.replay_ba, check)
+    # Life cycle of the remainder: the next relinearisation wave zeroes it and the handle goes back to its plain sweep (fused, or the
+    # staged one with 16-double rows again).  What that sweep leaves must be what update_all_beliefs re-sums from the stored messages.
+    for e in made.values():
+        e.set_iters_since_relin(8)
+        e.iterate(40)
+        assert e.info()['cam_groups'] == (1 if fused else 0)
+        before = e.beliefs()
+        e.update_all_beliefs()
+        assert max(rel_err_rows(a, b) for a, b in zip(before, e.beliefs())) < 1e-8
     for e in made.values():
         e.close()
 
