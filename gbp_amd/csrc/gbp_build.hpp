@@ -179,7 +179,6 @@ struct BuildArgs {
     const int *lrow0, *lptr;              // per landmark: first slot; offsets into lm2ref
     const int *lm2ref, *ref_cam, *ref_file;   // ref_file may be NULL (reference order == file order)
     const double *cam_means, *lmk_means, *meas;
-    unsigned *meta;
     int *ref2slot, *cpos;
 };
 
@@ -213,8 +212,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mr = max(mr, __shfl_down(mr, off, 64));
     if (lane == 0) a.tiles[t].w = mr;
-    p.state[slot] = state_pack(1, active ? rank : 0, false, false);
-    a.meta[slot] = active ? (((unsigned)cam << META_LMK_BITS) | (unsigned)(td.y > 0 ? l - td.x : 0)) : 0u;
+    slot_words(p, slot)[0] = active ? (((unsigned)cam << META_LMK_BITS) | (unsigned)(td.y > 0 ? l - td.x : 0)) : 0u;
+    set_slot_state(p, slot, state_pack(1, active ? rank : 0, false, false));
+    if (p.avar) p.avar[slot] = p.sigma2;                                                 // gbp.py:242
     a.cpos[slot] = active ? r : 0;
     if (!active) return;
     a.ref2slot[r] = slot;
@@ -225,7 +225,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
     for (int k = 0; k < 3; ++k) p.lin[lin_at(slot, ROW_X0 + 6 + k)] = a.lmk_means[(size_t)l * 3 + k];
     p.lin[lin_at(slot, ROW_Z)] = a.meas[(size_t)fi * 2];
     p.lin[lin_at(slot, ROW_Z + 1)] = a.meas[(size_t)fi * 2 + 1];
-    p.lin[lin_at(slot, ROW_AVAR)] = p.sigma2;                                            // gbp.py:242
 }
 
 // node.mu = initial estimate (gbp_ba.py:116,123); landmark records also carry their slot range

@@ -651,7 +651,6 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
 
     clk.mark("tile packing");
     // 5. per-slot data
-    unsigned *d_meta = nullptr;
     bool general_sweep = false;
     {
         const int n_wg = std::max(1, std::min(T, n_cus));
@@ -666,7 +665,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         const bool sparse = (double)F < staged_below * (double)n_wg * (double)C;
         if (sparse) h->flags |= GBP_FLAG_NO_FUSED;
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
-        const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0)) * sizeof(double) + 3 * S * sizeof(int)
+        const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0) + (p.loss != 0 ? 1 : 0)) * sizeof(double) + S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
                           + (size_t)std::max(C, 1) * (CAMREC + CBEL + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
@@ -676,13 +675,14 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     if (general_sweep && F > 0) { CHK(dev_alloc(h, &p.cstage, Fz * p.crow)); h->cstage_cap = p.crow; }   // out of the same arena (else: on first use, ensure_staging)
     CHK(dev_alloc(h, &p.lin, S * LIN_ROWS)); CHK(dev_alloc(h, &p.msg, S * MSG_ROWS));
     if (p.num_undamped == 0) CHK(dev_alloc(h, &p.xtra, S * XTRA_ROW));      // damped in the relinearising sweep: gbp_math.hpp header
-    CHK(dev_alloc(h, &p.state, S)); CHK(dev_alloc(h, &d_meta, S)); CHK(dev_alloc(h, &cpos, S));
+    if (p.loss != 0) CHK(dev_alloc(h, &p.avar, S));         // adaptive variances: robust losses only
+    CHK(dev_alloc(h, &cpos, S));
     CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
     CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
     CHK(dev_alloc(h, &p.cbelief, (size_t)std::max(C, 1) * CBEL));
-    p.meta = d_meta; p.tiles = d_tiles; p.cptr = cptr; p.cadj = cadj; p.cpos = cpos;
+    p.tiles = d_tiles; p.cptr = cptr; p.cadj = cadj; p.cpos = cpos;
     if (T) {
-        BuildArgs a{d_tiles, d_lrow0, lptr, lm2ref, h->d_ref_cam, ref_file, cam_means, lmk_means, meas, d_meta, cadj, cpos};
+        BuildArgs a{d_tiles, d_lrow0, lptr, lm2ref, h->d_ref_cam, ref_file, cam_means, lmk_means, meas, cadj, cpos};
         hipLaunchKernelGGL(k_build_tiles, dim3((T + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, h->stream, p, a);
     }
     clk.mark("allocs + k_build_tiles");
@@ -712,8 +712,8 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     HIPCHK(hipStreamSynchronize(h->stream));                // the staged inputs are released by the caller
     clk.mark("fused plan");
     if (getenv("GBP_PRINT_PTRS"))
-        fprintf(stderr, "[gbp ptrs] lin %p msg %p state %p meta %p lrec %p cbel %p tables %p\n", (void *)p.lin, (void *)p.msg, (void *)p.state,
-                (const void *)p.meta, (void *)p.lrec, (void *)p.cbel, (void *)h->fused.args.block_partials);
+        fprintf(stderr, "[gbp ptrs] lin %p msg %p lrec %p cbel %p tables %p\n", (void *)p.lin, (void *)p.msg, (void *)p.lrec, (void *)p.cbel,
+                (void *)h->fused.args.block_partials);
     return GBP_OK;
 }
 
@@ -1589,7 +1589,7 @@ int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
     ENTER(h);
     if (value < 0 || value > ITERS_MAX) return fail(GBP_EINVAL, "iters_since_relin %d outside [0, %d]", value, ITERS_MAX);
     const int n = h->p.T * WTILE;
-    if (n) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p.state, n, value);
+    if (n) hipLaunchKernelGGL(k_fill_iters, dim3(grid_for(n)), dim3(BLOCK), 0, h->stream, h->p, n, value);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }
@@ -1710,7 +1710,7 @@ std::vector<StatePart> state_parts(gbp_ba *h)
 {
     const Params &p = h->p;
     const size_t S = (size_t)p.T * WTILE;
-    return {{p.lin, S * LIN_ROWS * sizeof(double)}, {p.msg, S * MSG_ROWS * sizeof(double)}, {p.state, S * sizeof(int)},
+    return {{p.lin, S * LIN_ROWS * sizeof(double)}, {p.msg, S * MSG_ROWS * sizeof(double)}, {p.avar, p.avar ? S * sizeof(double) : 0},
             {p.lrec, (size_t)p.L * LREC * sizeof(double)}, {p.cbel, (size_t)p.C * CAMREC * sizeof(double)}, {p.cbelief, (size_t)p.C * CBEL * sizeof(double)},
             {p.cprior, (size_t)p.C * 27 * sizeof(double)}, {p.xtra, p.xtra ? S * XTRA_ROW * sizeof(double) : 0}};
 }
@@ -1735,7 +1735,7 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
-    hd.version = 5; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.version = 6; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
     hd.walk_parity = h->walk_parity; hd.reserved = h->p.xtra ? 1u : 0u;      // (1: the payload ends with the dense message remainder)
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
     CHK(graph_hash(h, &hd.graph_hash));
@@ -1810,7 +1810,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
     if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0) return fail(GBP_EINVAL, "not a GBP state blob (magic)");
-    if (hd.version == 5 && hd.F == h->p.F && hd.T == h->p.T) {      // the blob decides whether the handle carries a remainder
+    if (hd.version == 6 && hd.F == h->p.F && hd.T == h->p.T) {      // the blob decides whether the handle carries a remainder
         if ((hd.reserved & 1u) && !h->p.xtra) CHK(enable_remainder(h));
         if (!(hd.reserved & 1u) && h->p.xtra) {
             if (!h->lazy_xtra) return fail(GBP_EINVAL, "the state blob has no dense message remainder but this graph always carries one (num_undamped_iters = 0)");
@@ -1819,8 +1819,8 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     }
     uint64_t need = 0;
     CHK(gbp_ba_state_size(h, &need));
-    if (hd.version != 5)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances (records of 24 / 34 doubles)
-        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 5; INTEGRATION.md)", hd.version);
+    if (hd.version != 6)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances, 5: state / meta words in arrays of their own
+        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 6; INTEGRATION.md)", hd.version);
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)

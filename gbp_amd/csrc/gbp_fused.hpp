@@ -134,9 +134,9 @@ GBP_DEV void st1(double *__restrict__ base, unsigned byte_off, double x) { *rein
 
 // everything a tile's factors stream: six + five row pairs of the tile's block (16 bytes per lane each), the meta and state words
 struct TileStreams {
-    double2 a[6], m[5];
-    unsigned meta;
-    int st, cpos;
+    double2 a[6], m[5];       // a[5] = z[1] | {meta, state}
+    double avar;              // robust losses only
+    int cpos;
 };
 GBP_DEV double2 ld2_nt(const double *__restrict__ base, unsigned byte_off)
 {
@@ -150,15 +150,14 @@ GBP_DEV double2 ld2_nt(const double *__restrict__ base, unsigned byte_off)
 // headline size bypassing it costs +12...18 us); a larger graph sends past it what does not fit, so that the rest STAYS resident from
 // sweep to sweep instead of everything thrashing (fused_launch picks the bits from the sizes); the general sweep sends both past it
 // so that the cache keeps the staged camera rows for k_cam_partial_staged (126 against 132 us per sweep at 1M factors).
-template <bool STAGED>
+template <int LOSS, bool STAGED>
 GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int nt)
 {
+    if (LOSS != 0) s.avar = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.avar + (size_t)t * WTILE) + (unsigned)lane * 8u);
     if (STAGED) s.cpos = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.cpos + (size_t)t * WTILE) + (unsigned)lane * 4u);
     const double *lin_t = p.lin + (size_t)t * (LIN_ROWS * WTILE);
     const double *msg_t = p.msg + (size_t)t * (MSG_ROWS * WTILE);
     const unsigned lo = (unsigned)lane * 16u;             // byte offset of this lane's 16 bytes inside a row pair (1 KB per pair)
-    s.meta = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(p.meta + (size_t)t * WTILE) + (unsigned)lane * 4u);
-    s.st = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u);
     if (STAGED || (nt & 1)) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) s.a[k] = ld2_nt(lin_t, 1024u * k + lo);
@@ -238,14 +237,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        issue_streams<STAGED>(p, t, lane, S, a.nt);
+        issue_streams<LOSS, STAGED>(p, t, lane, S, a.nt);
         const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
-        const unsigned meta = S.meta;
-        int st = S.st;
+        const unsigned long long words = (unsigned long long)__double_as_longlong(S.a[5].y);      // meta (low) | state (high): gbp_kernels.hpp ROW_SM
+        const unsigned meta = (unsigned)words;
+        int st = (int)(words >> 32);
         x0[0] = S.a[0].x; x0[1] = S.a[0].y; x0[2] = S.a[1].x; x0[3] = S.a[1].y; x0[4] = S.a[2].x; x0[5] = S.a[2].y; x0[6] = S.a[3].x; x0[7] = S.a[3].y;
         x0[8] = S.a[4].x; z[0] = S.a[4].y; z[1] = S.a[5].x;
-        if (LOSS != 0) avar = S.a[5].y;
+        if (LOSS != 0) avar = S.avar;
         qC[0] = S.m[0].x; qC[1] = S.m[0].y; qL[0] = S.m[1].x; qL[1] = S.m[1].y;
         WC[0] = S.m[2].x; WC[1] = S.m[2].y; WC[2] = S.m[3].x; VL[0] = S.m[3].y; VL[1] = S.m[4].x; VL[2] = S.m[4].y;
         // the tile's descriptor, and the heads (mean | covariance | rows) of its landmark records: ten doubles of every twenty,
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             st2(msg_w, 2048u + lo, WC[0], WC[1]); st2(msg_w, 3072u + lo, WC[2], VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-            *reinterpret_cast<int *>(reinterpret_cast<char *>(p.state + (size_t)t * WTILE) + (unsigned)lane * 4u) = st;
-            if (LOSS != 0) st1(lin_w, 5120u + lo + 8u, avar);
+            *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;      // the state word: high half of ROW_SM
+            if (LOSS != 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(p.avar + (size_t)t * WTILE) + (unsigned)lane * 8u) = avar;
         }
         lmk_prefetch(p, lane, t, l0, nl, pre);             // priors | slot ranges for this tile's belief phase, one iteration from now
         if (STAGED) {

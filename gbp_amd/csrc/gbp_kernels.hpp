@@ -11,12 +11,13 @@
 // [row/2][64 lanes][2], so a lane owns 16 contiguous bytes per pair (one dwordx4 access):
 //     lin[tile][12][64]   rows 0-8 x0 = linearisation point (t, w, y)      Factor.linpoint      gbp.py:231
 //                         rows 9-10 z  = measurement                        Factor.measurement   gbp.py:233
-//                         row  11  adaptive noise variance (loss != none)   gbp.py:242
+//                         row  11  two 32-bit words: meta | state (below)   -- they arrive with z[1] in one 16-byte load
+//     avar[slot]          adaptive noise variance, robust losses only       gbp.py:242
 //     msg[tile][10][64]   rows 0-1 / 2-3 the coefficients q_C / q_L of the two message etas (eta = J^T q with J at x0),
 //                         rows 4-6 / 7-9 the 2x2 cores W / V of the two message precisions (Lambda = J^T Q J:
 //                         gbp_math.hpp rank2_update)                                  Factor.messages  gbp.py:222
-//     state[slot] int32 = iters_since_relin << 12 | rank << 2 | robust << 1 | damped     gbp.py:245-249
-//     meta[slot] uint32 = camera index << 8 | landmark's position inside its tile
+//     state word  int32 = iters_since_relin << 12 | pending << 11 | rank << 2 | robust << 1 | damped     gbp.py:245-249
+//     meta word  uint32 = camera index << 8 | landmark's position inside its tile
 // so a wave's access is one contiguous 1 KB line per row pair and a tile's whole working set is one
 // 5 KB + 6 KB block (the reference's dense messages would be 27 KB: eta 6 + 3, Lambda 6x6 + 3x3 per factor).  (Measured on MI355X, tools/membench.hip: the same bytes streamed as 83 separate
 // stride-F arrays reach 3.9 TB/s at 4 waves/CU, as tile-contiguous blocks 5.4 TB/s.)
@@ -43,7 +44,7 @@ namespace gbp {
 constexpr int WTILE = 64;         // slots per tile = lanes per wavefront
 constexpr int TILE_LMKS = 24;     // most landmarks a tile owns
 constexpr int LIN_ROWS = 12, MSG_ROWS = 10;
-constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_AVAR = 11;
+constexpr int ROW_X0 = 0, ROW_Z = 9, ROW_SM = 11;     // ROW_SM: 8 bytes = meta (low word) | state (high word), beside z[1] in the last pair
 constexpr int ROW_QC = 0, ROW_QL = 2, ROW_WC = 4, ROW_VL = 7;
 constexpr int XTRA_ROW = 9;       // doubles per slot of the dense remainder (num_undamped_iters = 0 only): camera 6 | landmark 3
 constexpr int LREC = 20;          // doubles per landmark record: mu 3 | Sigma 6 | rows | prior 9 | pad
@@ -67,9 +68,8 @@ struct Params {
     double sigma2, nstds, beta, eta_damping;
     int num_undamped, min_linear, loss;
     int robustify, local_relin;
-    double *lin, *msg;            // tile-blocked factor data
-    int *state;
-    const unsigned *meta;
+    double *lin, *msg;            // tile-blocked factor data (lin's last row carries the meta and state words: slot_words)
+    double *avar;                 // [slot] adaptive noise variance (gbp.py:242), or NULL when the loss is None (it is sigma^2 then)
     const int4 *tiles;            // {first landmark, landmarks owned, slots used, max rank}
     double *lrec;
     double *cbel, *cprior, *cbelief;
@@ -100,6 +100,14 @@ GBP_DEV void pin_scalars(Params &q)
 // 64 of them outstanding; 8-byte rows needed ~130 per tile)
 GBP_DEV size_t lin_at(int slot, int row) { return (((size_t)(slot >> 6) * (LIN_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
 GBP_DEV size_t msg_at(int slot, int row) { return (((size_t)(slot >> 6) * (MSG_ROWS / 2) + (row >> 1)) * WTILE + (slot & 63)) * 2 + (row & 1); }
+
+// The meta and state words of a slot share the double ROW_SM of the lin block (rounds 1-3 kept them in arrays of their own: 8 bytes per
+// slot and sweep more traffic, 8.5 MB more working set at 1M factors, two more loads per tile).
+GBP_DEV unsigned *slot_words(const Params &p, int slot) { return reinterpret_cast<unsigned *>(p.lin + lin_at(slot, ROW_SM)); }
+GBP_DEV unsigned slot_meta(const Params &p, int slot) { return slot_words(p, slot)[0]; }
+GBP_DEV int slot_state(const Params &p, int slot) { return (int)slot_words(p, slot)[1]; }
+GBP_DEV void set_slot_state(const Params &p, int slot, int st) { slot_words(p, slot)[1] = (unsigned)st; }
+GBP_DEV double slot_avar(const Params &p, int slot) { return p.avar ? p.avar[slot] : p.sigma2; }
 
 // state word: iters_since_relin << 12 | pending << 11 | rank << 2 | robust << 1 | damped.  "rank" (< 64) is constant per
 // factor: its index among the same-camera factors of its tile (fused sweep); every kernel carries it along.
@@ -336,7 +344,7 @@ GBP_DEV bool slot_info(const Params &p, int slot, int &cam, int &lmk)
 {
     const int4 td = p.tiles[slot >> 6];
     if ((slot & 63) >= td.z) return false;
-    const unsigned m = p.meta[slot];
+    const unsigned m = slot_meta(p, slot);
     cam = (int)(m >> META_LMK_BITS);
     lmk = td.x + (int)(m & ((1u << META_LMK_BITS) - 1u));
     return true;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     const int slot = t * WTILE + lane;
     double srow[XTRA ? CSTAGE_ROW : CSTAGE_PLAIN];          // x0 | q_C | W (| remainder, or two pad doubles) of this lane's factor AFTER the sweep
     if (active) {
-        const unsigned meta = p.meta[slot];
+        const unsigned meta = slot_meta(p, slot);
         const int cam = (int)(meta >> META_LMK_BITS), lmk = l0 + (int)(meta & ((1u << META_LMK_BITS) - 1u));
         double x0[9], z[2], qC[2], qL[2], WC[3], VL[3];
 #pragma unroll
@@ -478,8 +486,8 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
 #pragma unroll
         for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
-        int st = p.state[slot];
-        double avar = (LOSS != 0) ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+        int st = slot_state(p, slot);
+        double avar = (LOSS != 0) ? p.avar[slot] : p.sigma2;
         double muC[6], PC[21], muL[3];
         load_cam_record(p.cbel + (size_t)cam * CAMREC, muC, PC);
         const double *lr = p.lrec + (size_t)lmk * LREC;
@@ -512,8 +520,8 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eLn[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-        p.state[slot] = st;
-        if (LOSS != 0) p.lin[lin_at(slot, ROW_AVAR)] = avar;
+        set_slot_state(p, slot, st);
+        if (LOSS != 0) p.avar[slot] = avar;
         wp[lane] = p.cpos[slot];
 #pragma unroll
         for (int k = 0; k < 9; ++k) srow[k] = x0[k];
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void k_residual(Params p, double *__restrict
         project(x, p.K, h);
         const double r0 = h[0] - p.lin[lin_at(slot, ROW_Z)], r1 = h[1] - p.lin[lin_at(slot, ROW_Z + 1)];
         nr = sqrt(r0 * r0 + r1 * r1);
-        const double av = p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+        const double av = slot_avar(p, slot);
         en = 0.5 * (nr * nr) / av;
     }
 #pragma unroll
@@ -874,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) void k_factor_lambda_max(Params p, double *_
 #pragma unroll
     for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
     linearise(x0, p.K, Jc, Jl, h);
-    const double av = p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+    const double av = slot_avar(p, slot);
     fmax_out[slot] = factor_lambda_max(Jc, Jl, 1.0 / av);
 }
 
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(BLOCK) void k_factor_lambda_max(Params p, double *_
 GBP_DEV void effective_linpoint(const Params &p, int slot, double (&x0)[9])
 {
     int cam, lmk;
-    if ((p.state[slot] & STATE_PENDING) && slot_info(p, slot, cam, lmk)) {
+    if ((slot_state(p, slot) & STATE_PENDING) && slot_info(p, slot, cam, lmk)) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) x0[k] = p.cbel[(size_t)cam * CAMREC + CAM_MU + k];
 #pragma unroll
@@ -918,7 +926,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *_
         for (int k = 0; k < 9; ++k) acc += J[r][k] * x0[k];
         rho[r] = acc + zz[r] - h[r];
     }
-    const double s = 1.0 / (p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2);
+    const double s = 1.0 / slot_avar(p, slot);
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         eta_out[(size_t)i * 9 + a] = s * (J[0][a] * rho[0] + J[1][a] * rho[1]);
@@ -950,10 +958,10 @@ __global__ __launch_bounds__(BLOCK) void k_export_relin(Params p, const int *__r
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const int slot = slots[i], st = p.state[slot];
+    const int slot = slots[i], st = slot_state(p, slot);
     if (iters) iters[i] = state_iters(st);
     if (flags) flags[i] = (unsigned char)(st & 3);
-    if (avar) avar[i] = p.loss != 0 ? p.lin[lin_at(slot, ROW_AVAR)] : p.sigma2;
+    if (avar) avar[i] = slot_avar(p, slot);
 }
 
 // iters_since_relin of a list of slots (ba.py:91-93 per factor), clamped to the counter's range
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(BLOCK) void k_import_iters(Params p, const int *__r
     if (i >= n) return;
     const int slot = slots[i];
     const int v = min(max(iters[i], 0), ITERS_MAX);
-    p.state[slot] = (int)(((unsigned)v << STATE_SHIFT) | ((unsigned)p.state[slot] & ((1u << STATE_SHIFT) - 1u)));
+    set_slot_state(p, slot, (int)(((unsigned)v << STATE_SHIFT) | ((unsigned)slot_state(p, slot) & ((1u << STATE_SHIFT) - 1u))));
 }
 
 // number of factors whose iters_since_relin is 0 (the loop of ba.py:96-99), one atomic per workgroup
@@ -972,7 +980,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_relin(Params p, int *__restrict
     __shared__ int red[BLOCK / 64];
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
     int cam, lmk;
-    const bool hit = slot < p.T * WTILE && slot_info(p, slot, cam, lmk) && state_iters(p.state[slot]) == 0;
+    const bool hit = slot < p.T * WTILE && slot_info(p, slot, cam, lmk) && state_iters(slot_state(p, slot)) == 0;
     const unsigned long long b = __ballot(hit);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __popcll(b);
     __syncthreads();
@@ -999,11 +1007,11 @@ __global__ __launch_bounds__(BLOCK) void k_stage_robustify(Params p)
     double x0[9], h0[2];
     effective_linpoint(p, slot, x0);
     project(x0, p.K, h0);
-    int st = p.state[slot];
+    int st = slot_state(p, slot);
     bool robust = (st & 2) != 0;
     const double avar = robust_variance(LOSS, p.sigma2, p.nstds, p.lin[lin_at(slot, ROW_Z)] - h0[0], p.lin[lin_at(slot, ROW_Z + 1)] - h0[1], robust);
-    p.lin[lin_at(slot, ROW_AVAR)] = avar;
-    p.state[slot] = (st & ~2) | (robust ? 2 : 0);
+    p.avar[slot] = avar;
+    set_slot_state(p, slot, (st & ~2) | (robust ? 2 : 0));
 }
 
 // FactorGraph.relinearise_factors (gbp.py:64-80), or with mark_all FactorGraph.compute_all_factors (gbp.py:60-62: every factor,
@@ -1013,8 +1021,8 @@ __global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
     int cam, lmk;
     if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
-    int st = p.state[slot];
-    if (mark_all) { p.state[slot] = st | STATE_PENDING; return; }
+    int st = slot_state(p, slot);
+    if (mark_all) { set_slot_state(p, slot, st | STATE_PENDING); return; }
     int iters = state_iters(st);
     bool damped = (st & 1) != 0, pending = (st & STATE_PENDING) != 0;
     double d2 = 0.0;
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_
     }
     if (!pending && sqrt(d2) > p.beta && iters >= p.min_linear) { iters = 0; damped = false; pending = true; }
     else iters = min(iters + 1, ITERS_MAX);
-    p.state[slot] = state_pack(iters, state_rank(st), (st & 2) != 0, damped, pending);
+    set_slot_state(p, slot, state_pack(iters, state_rank(st), (st & 2) != 0, damped, pending));
 }
 
 // How many factors would be DAMPED in the very message computation that moves their linearisation point -- a pending relinearisation
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_pending_damped(Params p, int lo
     int cam, lmk;
     bool hit = false;
     if (slot < p.T * WTILE && slot_info(p, slot, cam, lmk)) {
-        const int st = p.state[slot];
+        const int st = slot_state(p, slot);
         if (st & STATE_PENDING) {
             int iters = state_iters(st);
             if (local_relin && !no_test) iters = min(iters + 1, ITERS_MAX);      // (a pending factor is not tested again: distance 0)
@@ -1136,10 +1144,10 @@ __global__ __launch_bounds__(BLOCK) void k_weaken_priors(Params p, double factor
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fill_iters(int *__restrict__ state, int n, int iters)
+__global__ __launch_bounds__(BLOCK) void k_fill_iters(Params p, int n, int iters)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) state[i] = (int)(((unsigned)min(max(iters, 0), ITERS_MAX) << STATE_SHIFT) | ((unsigned)state[i] & ((1u << STATE_SHIFT) - 1u)));
+    if (i < n) set_slot_state(p, i, (int)(((unsigned)min(max(iters, 0), ITERS_MAX) << STATE_SHIFT) | ((unsigned)slot_state(p, i) & ((1u << STATE_SHIFT) - 1u))));
 }
 
 }  // namespace gbp
