@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     // The landmark beliefs of a tile (LDS work, no loads) are formed one iteration LATE, after the next tile's loads have
     // been issued, so that the wave has HBM requests in flight meanwhile.  The tile's landmark messages wait in the wave's LDS
     // scratch, which the next tile overwrites only afterwards; the priors they are added to (one entry per lane and pass) and the
-    // landmarks' slot ranges are fetched at the end of the tile's own iteration and wait in nine registers.
+    // landmarks' slot ranges are fetched with the tile's own streams and wait in nine registers.
     bool pend = false;
     int q_l0 = 0, q_nl = 0;
     LmkPre pre;
@@ -264,6 +264,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             stage[j] = i < nhead2 ? lsrc[rec * (LREC / 2) + piece] : make_double2(0.0, 0.0);            // (heads: every other 80 bytes)
         }
 
+        // priors | slot ranges for THIS tile's belief phase, which runs one iteration from now: fetched with the tile's streams (a whole
+        // iteration of slack: beyond the memory-side cache they come from HBM, and fetched at the end of the iteration the belief phase
+        // of the next one waited for them)
+        LmkPre pre_next;
+        lmk_prefetch(p, lane, t, l0, nl, pre_next);
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;      // the state word: high half of ROW_SM
             if (LOSS != 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(p.avar + (size_t)t * WTILE) + (unsigned)lane * 8u) = avar;
         }
-        lmk_prefetch(p, lane, t, l0, nl, pre);             // priors | slot ranges for this tile's belief phase, one iteration from now
+        pre = pre_next;
         if (STAGED) {
             // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
             // transposed, eight whole 128-byte lines go out per instruction, 16 bytes per lane
