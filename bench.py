@@ -44,6 +44,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
 MIN_TIMED_S = 0.5
+STAMPS = 1 << 30              # gbp_ba_set_kernel_timing(STAMPS): device-clock stamps in every launch, HIP events around the first one only
 EVENT_EVERY = 7               # HIP events bracket every 7th launch of the dominant kernel in the instrumented replay (cross-check)
 MAX_BATCHES = 2000          # (a 20-step batch of a 15 us sweep is 0.3 ms: the cap only bounds degenerate cases)
 
@@ -391,11 +392,20 @@ def main():
 
         def batch(timing=0):
             """Restore the initial state, W untimed sweeps, then K sweeps between two fences.  Returns wall seconds (max over ranks)."""
+            stamps = timing == STAMPS
+            if stamps:                                             # before the warm-up: switching the stamps on costs host time
+                graph.set_kernel_timing(timing)
+            if timing and not dry:
+                # The host work around an instrumented replay (reading the stamps back, numpy) leaves the GPU idle for milliseconds; it
+                # drops its clocks, and a 20-sweep batch is over before they are back: on some boxes such replays measured sweeps 7 %
+                # longer than the timed batches they stand for.  Forty throw-away sweeps (the state is restored right after) put the
+                # clocks where a back-to-back batch finds them.
+                graph.iterate(40)
             if not dry:
                 graph.restore_snapshot()
             graph.iterate(args.warmup)
             graph.sync()
-            if timing:
+            if timing and not stamps:
                 graph.set_kernel_timing(timing)
             fence()
             t0 = time.perf_counter()
@@ -419,9 +429,23 @@ def main():
             # constant-rate clock (first workgroup in, last workgroup out), and HIP events bracket every EVENT_EVERY-th launch of
             # the dominant kernel as a cross-check (an event pair around a launch also times the dispatch behind the event's
             # barrier packet and serialises the stream, so it is neither put around every launch nor used for the roofline).
-            batch(timing=1 << 30)                              # stamps only (events around the first launch alone)
-            m['clk'] = graph.sweep_clocks()[:args.steps]
-            graph.set_kernel_timing(0)
+            # (A single replay can land on a slow patch -- one in a few is 5 % off the median batch -- so the replay is repeated and the
+            #  one whose device step is closest to the median batch time is the one reported: the picture of a TYPICAL batch.)
+            want_us = float(np.median(times)) / args.steps * 1e6
+            for rep in range(3):
+                batch(timing=STAMPS)                           # stamps only (events around the first launch alone)
+                clk = graph.sweep_clocks()[40 + args.warmup:40 + args.warmup + args.steps]      # (the throw-away and warm-up sweeps are stamped too)
+                graph.set_kernel_timing(0)
+                step_us = float(np.nanmean(np.diff(clk[:, 0]))) if clk.shape[0] > 1 else want_us
+                if rep == 0 or abs(step_us - want_us) < abs(best_us - want_us):
+                    m['clk'], best_us = clk, step_us
+                done = abs(best_us - want_us) <= 0.015 * want_us
+                if dist is not None:                           # (every rank runs the same number of replays: they contain barriers)
+                    t = torch.tensor([0.0 if done else 1.0], dtype=torch.float64, device=side_dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    done = float(t.item()) < 0.5
+                if done:
+                    break
             batch(timing=EVENT_EVERY)
             m['ev_ms'] = graph.kernel_times()
             _, _, m['k_name'] = graph.kernel_timing()
@@ -488,10 +512,11 @@ def main():
             g.generate_priors_var(50.0); g.update_all_beliefs(); g.sync(); g.snapshot_state()
             best = None
             for rep in range(3):
+                g.set_kernel_timing(STAMPS)                        # (before the warm-up, as in batch())
+                g.iterate(20)                                      # (clocks up: see batch())
                 g.restore_snapshot(); g.iterate(5); g.sync()
-                g.set_kernel_timing(1 << 30)
                 g.iterate(20); g.sync()
-                clk = g.sweep_clocks()[:20]
+                clk = g.sweep_clocks()[25:45]
                 g.set_kernel_timing(0)
                 k = float(np.nanmean((clk[:, 2] - clk[:, 0]) * 1e-3))
                 best = k if best is None else min(best, k)

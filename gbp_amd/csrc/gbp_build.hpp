@@ -213,7 +213,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
     for (int off = 32; off > 0; off >>= 1) mr = max(mr, __shfl_down(mr, off, 64));
     if (lane == 0) a.tiles[t].w = mr;
     slot_words(p, slot)[0] = active ? (((unsigned)cam << META_LMK_BITS) | (unsigned)(td.y > 0 ? l - td.x : 0)) : 0u;
-    set_slot_state(p, slot, state_pack(1, active ? rank : 0, false, false));
+    set_slot_state(p, slot, state_pack(1, p.clk, active ? rank : 0, false, false));      // iters_since_relin = 1, gbp.py:249
     if (p.avar) p.avar[slot] = p.sigma2;                                                 // gbp.py:242
     a.cpos[slot] = active ? r : 0;
     if (!active) return;

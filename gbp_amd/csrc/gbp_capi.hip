@@ -22,6 +22,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace gbp;
@@ -75,7 +76,7 @@ struct gbp_ba {
     int *d_big = nullptr;                        // the same on the device (general sweep)
     bool hash_ok = false; uint64_t hash = 0;     // digest of the layout (state blobs)
     void *arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
-    std::vector<void *> snap; std::vector<size_t> snap_bytes; bool snap_has_beliefs = false; uint32_t snap_parity = 0;   // device-resident checkpoint (gbp_ba_snapshot_state)
+    std::vector<void *> snap; std::vector<size_t> snap_bytes; bool snap_has_beliefs = false; uint32_t snap_parity = 0; int snap_clk = 0;   // device-resident checkpoint (gbp_ba_snapshot_state)
     // device scratch
     double *d_partial = nullptr;                 // C*27 camera partial sums (single-GPU path)
     double *d_red = nullptr;                     // per-block residual partials
@@ -108,6 +109,7 @@ struct gbp_ba {
     // device-clock stamps of instrumented sweeps: [CLK_RING][6] = {sweep start, end, reduce start, end, finish start, end}
     unsigned long long *d_clk = nullptr, *clk_cur = nullptr;
     int clk_used = 0, clk_rate_khz = 0;
+    bool clk_calibrated = false; double clk_rate_khz_measured = 0.0;      // the counter's real rate (gbp_ba_set_kernel_timing)
     // per-sweep count of relinearising factors: ring of device counters, half of it cleared whenever the sweep index
     // enters it, so the last RELIN_RING/2 sweeps are always readable
     int *d_relin_ring = nullptr;
@@ -209,6 +211,15 @@ static int download(gbp_ba *h, std::vector<T> &dst, const T *src, size_t n)
 }
 
 static inline int grid_for(size_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+// The relinearisation clock (gbp_kernels.hpp, state word): every call in which the reference's relinearise_factors() runs -- a sweep
+// with local_relin, or the stage call itself -- advances it by one; a factor's iters_since_relin is the clock minus the value its
+// state word holds.  Set before the launch: the kernels read the value AFTER the call's advance (Params::clk) and whether it advanced.
+static inline void clock_tick(gbp_ba *h, bool advance)
+{
+    h->p.clk_inc = advance ? 1 : 0;
+    if (advance) h->p.clk = (int)(((unsigned)h->p.clk + 1u) & CLK_MASK);
+}
 
 // ------------------------------------------------------------------------------ launches --
 
@@ -333,6 +344,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
     if (finished) *finished = false;
     h->clk_cur = (h->timing && h->d_clk && h->clk_used < CLK_RING) ? h->d_clk + 6 * (size_t)h->clk_used++ : nullptr;
     if (with_messages) {
+        clock_tick(h, local_relin != 0);
         const int slot = (int)(h->sweep_count % RELIN_RING);
         if (slot % (RELIN_RING / 2) == 0)
             HIPCHK(hipMemsetAsync(h->d_relin_ring + (size_t)slot * RELIN_LANES, 0, sizeof(int) * (RELIN_RING / 2) * RELIN_LANES, h->stream));
@@ -1023,6 +1035,7 @@ int gbp_ba_relinearise(gbp_ba_t *h)
     ENTER(h);
     h->resid_ok = false;
     if (!h->has_beliefs) return fail(GBP_ESTATE, "relinearise_factors needs beliefs (call update_all_beliefs first; the reference inverts zero matrices here, gbp.py:73)");
+    clock_tick(h, true);
     if (h->p.T) hipLaunchKernelGGL(k_stage_relinearise, dim3(grid_for(n_slots(h))), dim3(BLOCK), 0, h->stream, h->p, 0);
     HIPCHK(hipGetLastError());
     h->pending_possible = true;
@@ -1054,6 +1067,7 @@ int gbp_ba_compute_messages(gbp_ba_t *h, int32_t local_relin)
     h->p.relin_slot = h->d_relin_ring + (size_t)slot * RELIN_LANES;
     h->sweep_count++;
     h->p.stage = STAGE_NO_TEST | STAGE_NO_BELIEFS;
+    clock_tick(h, false);                                    // (no relinearisation test in this call: nobody ages)
     h->p.reverse_walk = 0;
     const int rc = launch_factor_stage(h, 0, local_relin);
     h->p.stage = 0;
@@ -1682,6 +1696,7 @@ struct StateHeader {
     char magic[8];                 // "GBPSTATE"
     uint32_t version, has_beliefs;
     uint32_t walk_parity, reserved;    // reserved: bit 0 = the blob carries the dense message remainder
+    uint32_t relin_clock, pad;         // the graph's relinearisation clock (the state words hold clock values: gbp_kernels.hpp)
     int32_t F, T, L, C;
     uint64_t graph_hash;           // digest of the factor -> (slot, camera, landmark) maps (k_graph_hash)
     uint64_t payload_bytes;
@@ -1735,8 +1750,9 @@ int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);
     StateHeader hd{};
     std::memcpy(hd.magic, "GBPSTATE", 8);
-    hd.version = 6; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
+    hd.version = 7; hd.has_beliefs = h->has_beliefs ? 1u : 0u;
     hd.walk_parity = h->walk_parity; hd.reserved = h->p.xtra ? 1u : 0u;      // (1: the payload ends with the dense message remainder)
+    hd.relin_clock = (uint32_t)h->p.clk; hd.pad = 0;
     hd.F = h->p.F; hd.T = h->p.T; hd.L = h->p.L; hd.C = h->p.C;
     CHK(graph_hash(h, &hd.graph_hash));
     hd.payload_bytes = need - sizeof(StateHeader);
@@ -1769,6 +1785,7 @@ int gbp_ba_snapshot_state(gbp_ba_t *h)
     }
     h->snap_has_beliefs = h->has_beliefs;
     h->snap_parity = h->walk_parity;
+    h->snap_clk = h->p.clk;
     return GBP_OK;
 }
 
@@ -1799,6 +1816,7 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h)
     h->has_beliefs = h->snap_has_beliefs;
     h->pending_possible = true;                              // (the restored state words may carry pending relinearisations)
     h->walk_parity = h->snap_parity;
+    h->p.clk = h->snap_clk; h->p.clk_inc = 0;
     return GBP_OK;
 }
 
@@ -1810,7 +1828,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
     if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0) return fail(GBP_EINVAL, "not a GBP state blob (magic)");
-    if (hd.version == 6 && hd.F == h->p.F && hd.T == h->p.T) {      // the blob decides whether the handle carries a remainder
+    if (hd.version == 7 && hd.F == h->p.F && hd.T == h->p.T) {      // the blob decides whether the handle carries a remainder
         if ((hd.reserved & 1u) && !h->p.xtra) CHK(enable_remainder(h));
         if (!(hd.reserved & 1u) && h->p.xtra) {
             if (!h->lazy_xtra) return fail(GBP_EINVAL, "the state blob has no dense message remainder but this graph always carries one (num_undamped_iters = 0)");
@@ -1819,8 +1837,8 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     }
     uint64_t need = 0;
     CHK(gbp_ba_state_size(h, &need));
-    if (hd.version != 6)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances, 5: state / meta words in arrays of their own
-        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 6; INTEGRATION.md)", hd.version);
+    if (hd.version != 7)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances, 5: state / meta words in arrays of their own, 6: iters_since_relin stored instead of clock values
+        return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 7; INTEGRATION.md)", hd.version);
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)
@@ -1835,6 +1853,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     h->has_beliefs = hd.has_beliefs != 0;
     h->pending_possible = true;                              // (the loaded state words may carry pending relinearisations)
     h->walk_parity = hd.walk_parity & 1u;
+    h->p.clk = (int)(hd.relin_clock & CLK_MASK); h->p.clk_inc = 0;
     return GBP_OK;
 }
 
@@ -1855,6 +1874,31 @@ int gbp_ba_set_kernel_timing(gbp_ba_t *h, int32_t enable)
             h->allocs.push_back(h->d_clk);
             HIPCHK(hipDeviceGetAttribute(&h->clk_rate_khz, hipDeviceAttributeWallClockRate, h->device));
         }
+        if (!h->clk_calibrated) {
+            // The rate of wall_clock64: hipDeviceAttributeWallClockRate says 100 MHz, and on some boxes of the pool the counter runs
+            // ~7 % faster than that (stamped kernel times came out longer than the step that contains them, while HIP events and the
+            // wall clock agreed with each other).  Measured once per handle: two stamps 20 ms apart against the HIP events around them.
+            unsigned long long *d_cal = nullptr, cal[2] = {0, 0};
+            hipEvent_t e0, e1;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_cal), 2 * sizeof(unsigned long long)));
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(k_clk_stamp, dim3(1), dim3(64), 0, h->stream, d_cal);
+            HIPCHK(hipEventRecord(e0, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            hipLaunchKernelGGL(k_clk_stamp, dim3(1), dim3(64), 0, h->stream, d_cal + 1);
+            HIPCHK(hipEventRecord(e1, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            HIPCHK(hipMemcpy(cal, d_cal, sizeof cal, hipMemcpyDeviceToHost));
+            (void)hipFree(d_cal); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            if (ms > 1.f && cal[1] > cal[0]) {
+                const double khz = (double)(cal[1] - cal[0]) / (double)ms;
+                if (khz > 0.5 * h->clk_rate_khz && khz < 2.0 * h->clk_rate_khz) h->clk_rate_khz_measured = khz;
+            }
+            h->clk_calibrated = true;
+        }
         hipLaunchKernelGGL(k_clk_init, dim3((6 * CLK_RING + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d_clk, 6 * CLK_RING);
         HIPCHK(hipGetLastError());
     }
@@ -1872,7 +1916,8 @@ int gbp_ba_get_sweep_clocks(gbp_ba_t *h, double *us6, int32_t cap, int32_t *n_sw
     CHK(download(h, raw, h->d_clk, 6 * (size_t)n));
     unsigned long long t0 = ~0ull;
     for (unsigned long long v : raw) if (v != 0ull && v != ~0ull) t0 = std::min(t0, v);
-    const double us_per_tick = h->clk_rate_khz > 0 ? 1e3 / (double)h->clk_rate_khz : 0.01;
+    const double khz = h->clk_rate_khz_measured > 0.0 ? h->clk_rate_khz_measured : (double)h->clk_rate_khz;
+    const double us_per_tick = khz > 0.0 ? 1e3 / khz : 0.01;
     for (int i = 0; i < n && i < cap; ++i)
         for (int k = 0; k < 6; ++k) {
             const unsigned long long v = raw[6 * (size_t)i + k];

@@ -329,7 +329,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             st2(msg_w, 2048u + lo, WC[0], WC[1]); st2(msg_w, 3072u + lo, WC[2], VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-            *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;      // the state word: high half of ROW_SM
+            if (st != (int)(words >> 32))                   // the state word (high half of ROW_SM): only a factor that did more than age has a new one
+                *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;
             if (LOSS != 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(p.avar + (size_t)t * WTILE) + (unsigned)lane * 8u) = avar;
         }
         pre = pre_next;

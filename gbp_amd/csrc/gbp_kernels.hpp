@@ -82,6 +82,7 @@ struct Params {
     int reverse_walk;             // general sweep: tiles and cameras are visited backwards (every other sweep; results do not depend on it)
     int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
     int stage;                    // 0: a whole synchronous_iteration.  STAGE_* bits: the reference's stage-wise entry points (gbp.py:46-84)
+    int clk, clk_inc;             // the graph's relinearisation clock AFTER this call, and whether this call advances it (state word below)
 };
 constexpr int STAGE_NO_TEST = 1;      // compute_all_messages alone: no relinearisation test, no iters_since_relin bookkeeping (gbp.py:46-54)
 constexpr int STAGE_NO_BELIEFS = 2;   // ... and no belief is touched (the reference updates them in update_all_beliefs only, gbp.py:56-58)
@@ -109,21 +110,33 @@ GBP_DEV int slot_state(const Params &p, int slot) { return (int)slot_words(p, sl
 GBP_DEV void set_slot_state(const Params &p, int slot, int st) { slot_words(p, slot)[1] = (unsigned)st; }
 GBP_DEV double slot_avar(const Params &p, int slot) { return p.avar ? p.avar[slot] : p.sigma2; }
 
-// state word: iters_since_relin << 12 | pending << 11 | rank << 2 | robust << 1 | damped.  "rank" (< 64) is constant per
-// factor: its index among the same-camera factors of its tile (fused sweep); every kernel carries it along.
+// state word: relinearisation clock << 12 | pending << 11 | rank << 2 | robust << 1 | damped.
+// iters_since_relin (gbp.py:249) is not stored: the reference adds one to it for EVERY factor in every relinearise_factors() call
+// (gbp.py:79-80) and zeroes it when the factor relinearises, so it is  (graph clock) - (clock value at the factor's last zero),  and the
+// word holds the latter (20 bits, modulo).  A factor that does nothing but age -- every factor of a steady sweep -- keeps its word, and
+// the sweep writes no state at all (rounds 1-3 stored the count itself: 4 bytes per factor and sweep written, on a 16-byte stride).
+// The clock (Params::clk) advances once per call that runs the relinearisation test; ages saturate at ITERS_MAX like the stored
+// counter did (only `>= min_linear` and `== num_undamped` are ever tested, both far below the cap, checked at create).
+// "rank" (< 64) is constant per factor: its index among the same-camera factors of its tile (fused sweep).
 // "pending": the factor has been told to linearise again at the belief means (relinearise_factors / compute_all_factors called on
 // their own, gbp.py:60-80) but its messages have not been recomputed since.  A message is stored as coefficients in the rows of the
 // Jacobian at the stored linearisation point, so the point moves when the messages are next computed -- at the belief means, which
 // cannot change before that (beliefs are sums of messages) -- and the views show the belief means as the linearisation point meanwhile.
 constexpr int STATE_SHIFT = 12;
+constexpr unsigned CLK_MASK = (1u << (32 - STATE_SHIFT)) - 1u;
 constexpr int ITERS_MAX = (1 << (31 - STATE_SHIFT)) - 1;     // iters_since_relin saturates here (524 287)
 constexpr unsigned STATE_RANK_MASK = 0x1ffu;
 constexpr int STATE_PENDING = 1 << 11;
-GBP_HD int state_iters(int st) { return st >> STATE_SHIFT; }
+GBP_HD int state_age(int st, int clk) { return (int)(((unsigned)clk - ((unsigned)st >> STATE_SHIFT)) & CLK_MASK); }     // iters_since_relin at clock `clk`
 GBP_HD int state_rank(int st) { return (st >> 2) & (int)STATE_RANK_MASK; }
-GBP_HD int state_pack(int iters, int rank, bool robust, bool damped, bool pending = false)
+GBP_HD int state_pack(int iters, int clk, int rank, bool robust, bool damped, bool pending = false)      // a factor whose age is `iters` at clock `clk`
 {
-    return (int)(((unsigned)iters << STATE_SHIFT) | (pending ? (unsigned)STATE_PENDING : 0u) | ((unsigned)rank << 2) | (robust ? 2u : 0u) | (damped ? 1u : 0u));
+    return (int)(((((unsigned)clk - (unsigned)iters) & CLK_MASK) << STATE_SHIFT) | (pending ? (unsigned)STATE_PENDING : 0u) | ((unsigned)rank << 2) |
+                 (robust ? 2u : 0u) | (damped ? 1u : 0u));
+}
+GBP_HD int state_set_age(int st, int iters, int clk)
+{
+    return (int)(((((unsigned)clk - (unsigned)iters) & CLK_MASK) << STATE_SHIFT) | ((unsigned)st & ((1u << STATE_SHIFT) - 1u)));
 }
 
 // Per-factor front of FactorGraph.synchronous_iteration (gbp.py:86-92): robustify (gbp.py:296-332), relinearisation
@@ -134,7 +147,7 @@ template <int LOSS>
 GBP_HD bool factor_decide(const Params &p, const double (&x0)[9], const double (&z)[2], int &st, double &avar,
                            const double (&muC)[6], const double (&muL)[3], double &d)
 {
-    int iters = state_iters(st);
+    int iters = state_age(st, p.clk - p.clk_inc);           // iters_since_relin before this call (state word header)
     bool robust = (st & 2) != 0, damped = (st & 1) != 0;
     const bool pending = (st & STATE_PENDING) != 0;          // told to relinearise earlier (stage-wise calls): the point moves now
     if (LOSS != 0 && p.robustify) {
@@ -162,16 +175,15 @@ GBP_HD bool factor_decide(const Params &p, const double (&x0)[9], const double (
             damped = false;
             relin = true;
         } else {
-            // saturating: the counter shares the int32 state word (20 bits); only `>= min_linear` and `== num_undamped`
-            // are ever tested, and both thresholds are far below the cap (checked at create), so a converged factor that
-            // never relinearises behaves like the reference's unbounded Python int for ever
+            // saturating (state word header): a converged factor that never relinearises behaves like the reference's unbounded
+            // Python int for ever
             iters = min(iters + 1, ITERS_MAX);
         }
     }
     if (p.local_relin && iters == p.num_undamped) damped = true;      // gbp.py:50-51 (equality, not >=)
     relin = relin || pending;
     d = p.local_relin ? (damped ? p.eta_damping : 0.0) : p.eta_damping;   // gbp.py:52-54
-    st = state_pack(iters, state_rank(st), robust, damped);
+    st = state_pack(iters, p.clk, state_rank(st), robust, damped);      // (the word of a factor that has only aged is unchanged)
     return relin;
 }
 
@@ -487,6 +499,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 #pragma unroll
         for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
         int st = slot_state(p, slot);
+        const int st_in = st;
         double avar = (LOSS != 0) ? p.avar[slot] : p.sigma2;
         double muC[6], PC[21], muL[3];
         load_cam_record(p.cbel + (size_t)cam * CAMREC, muC, PC);
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
         for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eLn[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-        set_slot_state(p, slot, st);
+        if (st != st_in) set_slot_state(p, slot, st);
         if (LOSS != 0) p.avar[slot] = avar;
         wp[lane] = p.cpos[slot];
 #pragma unroll
@@ -829,6 +842,12 @@ __global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const dou
     cam_finish_wave(p, gathered, n_parts, part_stride, wait, c, lane);
 }
 
+// instrumented runs: one stamp of the device's constant-rate clock (the calibration of gbp_ba_set_kernel_timing)
+__global__ void k_clk_stamp(unsigned long long *out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = (unsigned long long)wall_clock64();
+}
+
 // instrumented runs: the stamp ring starts empty
 __global__ void k_clk_init(unsigned long long *clk, int n)
 {
@@ -959,7 +978,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_relin(Params p, const int *__r
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const int slot = slots[i], st = slot_state(p, slot);
-    if (iters) iters[i] = state_iters(st);
+    if (iters) iters[i] = state_age(st, p.clk);
     if (flags) flags[i] = (unsigned char)(st & 3);
     if (avar) avar[i] = slot_avar(p, slot);
 }
@@ -971,7 +990,7 @@ __global__ __launch_bounds__(BLOCK) void k_import_iters(Params p, const int *__r
     if (i >= n) return;
     const int slot = slots[i];
     const int v = min(max(iters[i], 0), ITERS_MAX);
-    set_slot_state(p, slot, (int)(((unsigned)v << STATE_SHIFT) | ((unsigned)slot_state(p, slot) & ((1u << STATE_SHIFT) - 1u))));
+    set_slot_state(p, slot, state_set_age(slot_state(p, slot), v, p.clk));
 }
 
 // number of factors whose iters_since_relin is 0 (the loop of ba.py:96-99), one atomic per workgroup
@@ -980,7 +999,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_relin(Params p, int *__restrict
     __shared__ int red[BLOCK / 64];
     const int slot = blockIdx.x * BLOCK + threadIdx.x;
     int cam, lmk;
-    const bool hit = slot < p.T * WTILE && slot_info(p, slot, cam, lmk) && state_iters(slot_state(p, slot)) == 0;
+    const bool hit = slot < p.T * WTILE && slot_info(p, slot, cam, lmk) && state_age(slot_state(p, slot), p.clk) == 0;
     const unsigned long long b = __ballot(hit);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __popcll(b);
     __syncthreads();
@@ -1023,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_
     if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
     int st = slot_state(p, slot);
     if (mark_all) { set_slot_state(p, slot, st | STATE_PENDING); return; }
-    int iters = state_iters(st);
+    int iters = state_age(st, p.clk - 1);                    // (the host has advanced the clock for this call)
     bool damped = (st & 1) != 0, pending = (st & STATE_PENDING) != 0;
     double d2 = 0.0;
     if (!pending) {
@@ -1034,7 +1053,8 @@ __global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_
     }
     if (!pending && sqrt(d2) > p.beta && iters >= p.min_linear) { iters = 0; damped = false; pending = true; }
     else iters = min(iters + 1, ITERS_MAX);
-    set_slot_state(p, slot, state_pack(iters, state_rank(st), (st & 2) != 0, damped, pending));
+    const int st_new = state_pack(iters, p.clk, state_rank(st), (st & 2) != 0, damped, pending);
+    if (st_new != st) set_slot_state(p, slot, st_new);
 }
 
 // How many factors would be DAMPED in the very message computation that moves their linearisation point -- a pending relinearisation
@@ -1049,7 +1069,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_pending_damped(Params p, int lo
     if (slot < p.T * WTILE && slot_info(p, slot, cam, lmk)) {
         const int st = slot_state(p, slot);
         if (st & STATE_PENDING) {
-            int iters = state_iters(st);
+            int iters = state_age(st, p.clk);
             if (local_relin && !no_test) iters = min(iters + 1, ITERS_MAX);      // (a pending factor is not tested again: distance 0)
             const bool damped = (st & 1) != 0 || (local_relin && iters == p.num_undamped);
             hit = local_relin ? damped : true;
@@ -1147,7 +1167,7 @@ __global__ __launch_bounds__(BLOCK) void k_weaken_priors(Params p, double factor
 __global__ __launch_bounds__(BLOCK) void k_fill_iters(Params p, int n, int iters)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) set_slot_state(p, i, (int)(((unsigned)min(max(iters, 0), ITERS_MAX) << STATE_SHIFT) | ((unsigned)slot_state(p, i) & ((1u << STATE_SHIFT) - 1u))));
+    if (i < n) set_slot_state(p, i, state_set_age(slot_state(p, i), min(max(iters, 0), ITERS_MAX), p.clk));
 }
 
 }  // namespace gbp

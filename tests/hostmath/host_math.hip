@@ -37,7 +37,7 @@ extern "C" {
 
 // one sweep's per-factor part (robustify, relinearisation test, linearisation, both messages) over n factors; st = the state words
 int hm_sweep_factors(int n, const double *K4, double sigma2, double nstds, double beta, double eta_damping, int num_undamped, int min_linear,
-                     int loss, int robustify, int local_relin, int stage, double *x0, const double *z, int *st, double *avar, const double *muC,
+                     int loss, int robustify, int local_relin, int stage, int clk, int clk_inc, double *x0, const double *z, int *st, double *avar, const double *muC,
                      const double *PC, const double *muL, const double *PL, double *qC, double *qL, double *WC, double *VL, double *eC, double *MC,
                      double *eL, double *ML, double *xt, int *relin)
 {
@@ -45,6 +45,7 @@ int hm_sweep_factors(int n, const double *K4, double sigma2, double nstds, doubl
     p.K = Intrinsics{K4[0], K4[1], K4[2], K4[3]};
     p.sigma2 = sigma2; p.nstds = nstds; p.beta = beta; p.eta_damping = eta_damping;
     p.num_undamped = num_undamped; p.min_linear = min_linear; p.loss = loss; p.robustify = robustify; p.local_relin = local_relin; p.stage = stage;
+    p.clk = clk; p.clk_inc = clk_inc;                        // the relinearisation clock after this call, and whether the call advances it
 #define GO(L, X) run<L, X>(n, p, x0, z, st, avar, muC, PC, muL, PL, qC, qL, WC, VL, eC, MC, eL, ML, xt, relin)
     if (xt) { if (loss == 0) GO(0, true); else if (loss == 1) GO(1, true); else GO(2, true); }
     else { if (loss == 0) GO(0, false); else if (loss == 1) GO(1, false); else GO(2, false); }
@@ -75,7 +76,8 @@ int hm_belief(int dofs, int n, const double *eta, const double *lam, double *mu,
     return 0;
 }
 
-int hm_state_pack(int iters, int rank, int robust, int damped, int pending) { return state_pack(iters, rank, robust != 0, damped != 0, pending != 0); }
-int hm_state_iters(int st) { return state_iters(st); }
+int hm_state_pack(int iters, int clk, int rank, int robust, int damped, int pending) { return state_pack(iters, clk, rank, robust != 0, damped != 0, pending != 0); }
+int hm_state_age(int st, int clk) { return state_age(st, clk); }
+int hm_state_set_age(int st, int iters, int clk) { return state_set_age(st, iters, clk); }
 
 }  // extern "C"

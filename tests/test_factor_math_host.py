@@ -59,7 +59,8 @@ class HostBA:
                         loss={None: 0, 'huber': 1, 'constant': 2}[loss])
         F = self.F
         self.x0 = np.ascontiguousarray(np.concatenate([prob.cam_means[self.cam], prob.lmk_means[self.lmk]], axis=1))
-        self.st = np.full(F, lib.hm_state_pack(1, 0, 0, 0, 0), np.int32)       # iters_since_relin = 1, gbp.py:249
+        self.clk = 0                                                             # the graph's relinearisation clock (gbp_kernels.hpp, state word)
+        self.st = np.full(F, lib.hm_state_pack(1, 0, 0, 0, 0, 0), np.int32)    # iters_since_relin = 1, gbp.py:249
         self.avar = np.full(F, self.sigma2)
         self.qC, self.qL, self.WC, self.VL = np.zeros((F, 2)), np.zeros((F, 2)), np.zeros((F, 3)), np.zeros((F, 3))
         self.xt = np.zeros((F, 9)) if num_undamped_iters == 0 else None
@@ -97,7 +98,8 @@ class HostBA:
         self.lib.hm_belief(3, self.L, d(np.ascontiguousarray(lb[:, :3])), d(np.ascontiguousarray(lb[:, 3:])), d(self.lmk_mu), d(self.lmk_P))
 
     def set_iters_since_relin(self, v):
-        self.st = ((self.st & 0xfff) | (int(v) << 12)).astype(np.int32)
+        rc = (self.clk - int(v)) & 0xfffff
+        self.st = ((self.st.astype(np.int64) & 0xfff) | (rc << 12)).astype(np.uint32).view(np.int32)
 
     def synchronous_iteration(self, robustify=True, local_relin=True):
         muC, PC = np.ascontiguousarray(self.cam_mu[self.cam]), np.ascontiguousarray(self.cam_P[self.cam])
@@ -105,9 +107,11 @@ class HostBA:
         relin = np.zeros(self.F, np.int32)
         p = self.par
         c_d, c_i = ct.c_double, ct.c_int
+        if local_relin:
+            self.clk = (self.clk + 1) & 0xfffff
         self.lib.hm_sweep_factors(c_i(self.F), d(self.K), c_d(self.sigma2), c_d(p['nstds']), c_d(p['beta']), c_d(p['eta_damping']),
                                   c_i(p['num_undamped']), c_i(p['min_linear']), c_i(p['loss']), c_i(int(robustify)), c_i(int(local_relin)), c_i(0),
-                                  d(self.x0), d(self.z), self.st.ctypes.data_as(_ip), d(self.avar), d(muC), d(PC), d(muL), d(PL),
+                                  c_i(self.clk), c_i(int(bool(local_relin))), d(self.x0), d(self.z), self.st.ctypes.data_as(_ip), d(self.avar), d(muC), d(PC), d(muL), d(PL),
                                   d(self.qC), d(self.qL), d(self.WC), d(self.VL), d(self.eC), d(self.MC), d(self.eL), d(self.ML),
                                   d(self.xt) if self.xt is not None else None, relin.ctypes.data_as(_ip))
         self.update_all_beliefs()
@@ -117,7 +121,7 @@ class HostBA:
         return self.cbel[:, :6], unpack(self.cbel[:, 6:], 6), self.lbel[:, :3], unpack(self.lbel[:, 3:], 3)
 
     def iters(self):
-        return self.st >> 12
+        return (self.clk - (self.st.view(np.uint32).astype(np.int64) >> 12)) & 0xfffff
 
 
 def run_pair(hm, oracle_mod, name, sweeps, wf=50.0, float_impl=False, local_relin=True, **kw):
