@@ -46,6 +46,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI35
 MIN_TIMED_S = 0.5
 STAMPS = 1 << 30              # gbp_ba_set_kernel_timing(STAMPS): device-clock stamps in every launch, HIP events around the first one only
 EVENT_EVERY = 7               # HIP events bracket every 7th launch of the dominant kernel in the instrumented replay (cross-check)
+CLK_RING = 4096               # sweeps the library keeps stamps for (gbp_capi.hip)
 MAX_BATCHES = 2000          # (a 20-step batch of a 15 us sweep is 0.3 ms: the cap only bounds degenerate cases)
 
 
@@ -390,17 +391,19 @@ def main():
         if not dry:
             graph.snapshot_state()                             # device-resident: restoring it leaves no idle gap before the sweeps
 
+        spin = [0]                                             # throw-away sweeps ahead of an instrumented replay (set below)
+
         def batch(timing=0):
             """Restore the initial state, W untimed sweeps, then K sweeps between two fences.  Returns wall seconds (max over ranks)."""
             stamps = timing == STAMPS
             if stamps:                                             # before the warm-up: switching the stamps on costs host time
                 graph.set_kernel_timing(timing)
             if timing and not dry:
-                # The host work around an instrumented replay (reading the stamps back, numpy) leaves the GPU idle for milliseconds; it
-                # drops its clocks, and a 20-sweep batch is over before they are back: on some boxes such replays measured sweeps 7 %
-                # longer than the timed batches they stand for.  Forty throw-away sweeps (the state is restored right after) put the
-                # clocks where a back-to-back batch finds them.
-                graph.iterate(40)
+                # The host work around an instrumented replay (switching the stamps on, reading them back, numpy) leaves the GPU idle
+                # for milliseconds; it drops its clocks, and a 20-sweep batch is over before they are back: such replays measured
+                # sweeps 4-9 % longer than the timed batches they stand for.  About 25 ms of throw-away sweeps (the state is restored
+                # right after) put the clocks where the back-to-back timed batches find them.
+                graph.iterate(spin[0])
             if not dry:
                 graph.restore_snapshot()
             graph.iterate(args.warmup)
@@ -432,9 +435,10 @@ def main():
             # (A single replay can land on a slow patch -- one in a few is 5 % off the median batch -- so the replay is repeated and the
             #  one whose device step is closest to the median batch time is the one reported: the picture of a TYPICAL batch.)
             want_us = float(np.median(times)) / args.steps * 1e6
+            spin[0] = int(min(max(40, 25e3 / want_us), max(0, CLK_RING - args.warmup - args.steps)))
             for rep in range(3):
                 batch(timing=STAMPS)                           # stamps only (events around the first launch alone)
-                clk = graph.sweep_clocks()[40 + args.warmup:40 + args.warmup + args.steps]      # (the throw-away and warm-up sweeps are stamped too)
+                clk = graph.sweep_clocks()[spin[0] + args.warmup:spin[0] + args.warmup + args.steps]      # (the throw-away and warm-up sweeps are stamped too)
                 graph.set_kernel_timing(0)
                 step_us = float(np.nanmean(np.diff(clk[:, 0]))) if clk.shape[0] > 1 else want_us
                 if rep == 0 or abs(step_us - want_us) < abs(best_us - want_us):
@@ -513,10 +517,10 @@ def main():
             best = None
             for rep in range(3):
                 g.set_kernel_timing(STAMPS)                        # (before the warm-up, as in batch())
-                g.iterate(20)                                      # (clocks up: see batch())
+                g.iterate(160)                                     # (clocks up: see batch())
                 g.restore_snapshot(); g.iterate(5); g.sync()
                 g.iterate(20); g.sync()
-                clk = g.sweep_clocks()[25:45]
+                clk = g.sweep_clocks()[165:185]
                 g.set_kernel_timing(0)
                 k = float(np.nanmean((clk[:, 2] - clk[:, 0]) * 1e-3))
                 best = k if best is None else min(best, k)
