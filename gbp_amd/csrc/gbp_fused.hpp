@@ -273,7 +273,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
         // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
+#if !(defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 2)
         if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
+#endif
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(2);                                  // landmark beliefs of the previous tile (LDS)
 
@@ -322,6 +324,19 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
                                                         qC, qL, WC, VL, eC, eL, MCn, MLn);
             n_relin += relin_in_wave(relin);
             GBP_PH_NOWAIT(6);                              // the maths
+#if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1        // (this half's share of the stores: q_L, V_L)
+            st2(msg_w, 1024u + lo, qL[0], qL[1]);
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
+            st1(msg_w, 3072u + lo + 8u, VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
+#elif defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 2      // (q_C, W_C)
+            st2(msg_w, lo, qC[0], qC[1]);
+            wave_lds_sync();
+            st2(msg_w, 2048u + lo, WC[0], WC[1]); st1(msg_w, 3072u + lo, WC[2]);
+#else
             st2(msg_w, lo, qC[0], qC[1]); st2(msg_w, 1024u + lo, qL[0], qL[1]);
             wave_lds_sync();                               // every lane of the tile has read its landmark head
 #pragma unroll
@@ -329,6 +344,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             st2(msg_w, 2048u + lo, WC[0], WC[1]); st2(msg_w, 3072u + lo, WC[2], VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
+#endif
             if (st != (int)(words >> 32))                   // the state word (high half of ROW_SM): only a factor that did more than age has a new one
                 *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;
             if (LOSS != 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(p.avar + (size_t)t * WTILE) + (unsigned)lane * 8u) = avar;
@@ -361,7 +377,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         const int rank = state_rank(st);
         const int cloc = cam - a.cam_base;
         const bool mine = active && (unsigned)cloc < (unsigned)a.cam_count;
+#if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1
+        for (int r = 0; r < 0; ++r) {
+#else
         for (int r = 0; r <= ((a.dbg & 32) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
+#endif
             if (mine && rank == r && !(a.dbg & 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
                 double *dst = acc + cloc * 27;
 #pragma unroll

@@ -243,8 +243,12 @@ GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], 
             for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
             store_x0(x0);                                  // at once: the stores' operands do not travel through the eliminations
         }
+#if !(defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 1))
         downdate<3>(PL, muL, L.Jl[0], L.Jl[1], VL, qL);
+#endif
+#if !(defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 2))
         downdate<6>(PC, muC, L.Jc[0], L.Jc[1], WC, qC);
+#endif
         if (XTRA) {
             // e_old = J_old^T q_old + x_old: the remainder leaves the cavity too (mu' -= P' x_old).  Damped in the very sweep it
             // relinearises: d e_old leaves the span of the new Jacobian and is carried densely; otherwise only the old remainder decays.
@@ -279,14 +283,35 @@ GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], 
         qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0;
     }
     double Vn[3], Wn[3], rL[2], rC[2];
+    // GBP_EXPERIMENT_HALF (timing and register-budget experiment only, wrong results): 1 = only the camera-eliminating half of a factor
+    // (message to the landmark), 2 = only the landmark-eliminating half (message to the camera) -- what each wave of a two-waves-per-tile
+    // split would run; 3 = neither (the loop's skeleton: streams, gathers, staging, stores, ordered section) (profiles/r04_factor_halves.json).
+#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 1)
+    Wn[0] = WC[0]; Wn[1] = WC[1]; Wn[2] = WC[2]; rC[0] = qC[0]; rC[1] = qC[1];
+#else
     eliminate<3>(PL, muL, L.Jl[0], L.Jl[1], VL, qL, L.rho, L.s, Wn, rC);      // landmark out: the message to the camera
+#endif
+#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 2)
+    Vn[0] = VL[0]; Vn[1] = VL[1]; Vn[2] = VL[2]; rL[0] = qL[0]; rL[1] = qL[1];
+#else
     eliminate<6>(PC, muC, L.Jc[0], L.Jc[1], WC, qC, L.rho, L.s, Vn, rL);      // camera out: the message to the landmark
+#endif
     qL[0] = (1.0 - d) * rL[0] + dqL[0]; qL[1] = (1.0 - d) * rL[1] + dqL[1];
     qC[0] = (1.0 - d) * rC[0] + dqC[0]; qC[1] = (1.0 - d) * rC[1] + dqC[1];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { VL[k] = Vn[k]; WC[k] = Wn[k]; }
+#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 2)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { MLn[k] = 0.0; if (k < 3) eLn[k] = 0.0; }
+#else
     dense_message<3>(L.Jl[0], L.Jl[1], qL, VL, eLn, MLn);
+#endif
+#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 1)
+#pragma unroll
+    for (int k = 0; k < 21; ++k) { MCn[k] = 0.0; if (k < 6) eCn[k] = 0.0; }
+#else
     dense_message<6>(L.Jc[0], L.Jc[1], qC, WC, eCn, MCn);
+#endif
     if (XTRA) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { eCn[i] += xn[i]; xt[i] = xn[i]; }

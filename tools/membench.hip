@@ -7,9 +7,16 @@
 // hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o /tmp/membench && /tmp/membench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
-constexpr int R = 47, W = 36;
+#ifndef MB_R
+#define MB_R 47
+#endif
+#ifndef MB_W
+#define MB_W 36
+#endif
+constexpr int R = MB_R, W = MB_W;      // -DMB_R=22 -DMB_W=10: the fused sweep's rows per factor (round 4 layout)
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_stream(const double *__restrict__ in, double *__restrict__ out, int F, int waves_total)
@@ -79,14 +86,15 @@ static double time_ms(Fn fn, int reps = 20)
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int F = 1 << 20;
+    const int F = argc > 1 ? atoi(argv[1]) : 1 << 20;      // factors (multiple of 64)
     double *in, *out;
     hipMalloc(&in, sizeof(double) * (size_t)(R + 1) * F);
     hipMalloc(&out, sizeof(double) * (size_t)W * F);
     hipMemset(in, 0, sizeof(double) * (size_t)(R + 1) * F);
     const double bytes = 8.0 * F * (R + W);
+    printf("F = %d, %d rows in, %d out: %.0f MB per pass\n", F, R, W, 8e-6 * F * (R + W));
     for (int wpc : {4, 8, 16, 32}) {
         const int blocks = 256 * wpc / 4, waves = blocks * 4;
         double a = time_ms([&] { hipLaunchKernelGGL(k_stream<0>, dim3(blocks), dim3(256), 0, 0, in, out, F, waves); });
