@@ -177,3 +177,16 @@ def test_host_sweeps_global_damping(hm, oracle_mod):
     """local_relin=False: no relinearisation test, every message damped (gbp.py:52-54)."""
     worst, n_relin, _, _ = run_pair(hm, oracle_mod, 'fr1desk_vsmall.txt', 8, local_relin=False)
     assert n_relin == 0 and worst < 1e-6, worst
+
+
+def test_relinearisation_clock_wraps(hm):
+    """The state word stores the clock value of the last relinearisation (20 bits): ages survive the clock's wrap-around."""
+    mask = (1 << 20) - 1
+    for clk in (0, 3, mask - 1, mask):
+        for iters in (0, 1, 7, (1 << 19) - 1):
+            st = hm.hm_state_pack(iters, clk, 5, 1, 0, 0)
+            assert hm.hm_state_age(st, clk) == iters
+            assert hm.hm_state_age(st, (clk + 9) & mask) == iters + 9 or iters + 9 > mask
+            assert (st >> 2) & 0x1ff == 5 and (st & 3) == 2
+            st2 = hm.hm_state_set_age(st, 1, (clk + 2) & mask)
+            assert hm.hm_state_age(st2, (clk + 2) & mask) == 1 and (st2 & 0xfff) == (st & 0xfff)
