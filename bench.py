@@ -57,7 +57,8 @@ def survey_bytes(F, L, C):
 
 def layout_bytes(F, L, C, n_blocks, fused):
     """Bytes one launch of the dominant kernel must move in THIS engine's layout."""
-    per_factor = (21 + 10) * 8 + 12       # x0 9 z 2 | messages 10 in, 10 out | meta 4 B, state 4 B in + 4 B out
+    per_factor = (21 + 10) * 8 + 8        # x0 9 z 2 | messages 10 in, 10 out | meta 4 B + state 4 B in (a factor that only ages writes no state:
+                                          # the word holds the clock value of its last relinearisation; PMC write traffic 138 -> 119 MB)
     per_lmk = 20 * 8 + 9 * 8              # record (mean 3 | covariance 6 | rows | prior 9 | pad) in, mean | covariance out
     if fused:                             # k_sweep_wat: + one table row (27 sums + 1 pad double) per camera and workgroup out
         return F * per_factor + L * per_lmk + n_blocks * C * 28 * 8
@@ -570,7 +571,7 @@ def main():
         lib_hash = None if dry else library_fingerprint()
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": m['k_name'], "bytes_per_launch": lay,
-                "bytes_model": "engine layout, DESIGN.md section 4: F*(31 doubles + 12 B) + L*29 doubles + camera tables",
+                "bytes_model": "engine layout, DESIGN.md section 4: F*(31 doubles + 8 B) + L*29 doubles + camera tables",
                 "library_sha256_16": lib_hash,
                 "kernel_avg_ms": k_steady, "kernel_median_ms": k_med, "kernel_min_ms": k_min,
                 "kernel_launches_timed": n_steady, "kernel_timing": k_src,

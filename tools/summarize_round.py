@@ -40,6 +40,21 @@ def bench_line(path):
     return None
 
 
+def trace_timed_batch(name, sub, steps, warmup):
+    """The K launches of kernel `sub` in bench.py's ONE timed batch (--single-batch: batch 0 is untimed, batch 1 is timed; each is
+    W warm-up + K sweeps from the same restored state) -- the very sweeps bench.py's instrumented replay stamps, so the two averages
+    must agree.  (Launches further on belong to the replays and their throw-away sweeps, which continue from wherever the state is.)"""
+    import numpy as np
+    for f in glob.glob(os.path.join(out, name, '**', '*kernel_trace.csv'), recursive=True):
+        rows = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(f)) if sub in r['Kernel_Name'])
+        d = np.array([e - s for s, e in rows], dtype=float)[steps + 2 * warmup:2 * (steps + warmup)]
+        if d.size == steps:
+            med = float(np.median(d))
+            return {"launches": int(d.size), "mean_us": float(d.mean()) / 1e3, "median_us": med / 1e3,
+                    "steady_mean_us": float(d[d < 1.05 * med].mean()) / 1e3, "steady_launches": int((d < 1.05 * med).sum())}
+    return None
+
+
 def trace_summary(name, sub, per_batch):
     """From the kernel trace of a --stats run: durations of the launches of kernel `sub`, without the first batch (bench.py's untimed
     batch, clocks still ramping): mean, median, and the mean of the launches within 5 % of the median (steady sweeps: relinearising
@@ -90,6 +105,10 @@ for size, F, L, C in (('1m', 1_000_000, 100_000, 500), ('10m', 10_000_000, 1_000
             t["kernel_avg_us_rocprofv3"] = ka[0] / 1e3
             t["kernel_calls"] = ka[1]
             ts = trace_summary('stats_' + size, 'k_sweep_wat', (line or {}).get('steps', 200) + (line or {}).get('warmup', 20))
+            tb = trace_timed_batch('stats_' + size, 'k_sweep_wat', (line or {}).get('steps', 200), (line or {}).get('warmup', 20))
+            if tb:
+                t["rocprofv3_trace_timed_batch"] = tb
+                t["layout_frac_on_rocprofv3_timed_batch_mean"] = line["roofline"]["bytes_per_launch"] / (tb["mean_us"] * 1e3) / 8000.0 if line else None
             if ts:
                 t["rocprofv3_trace_without_first_batch"] = ts
                 t["layout_frac_on_rocprofv3_steady_mean"] = line["roofline"]["bytes_per_launch"] / (ts["steady_mean_us"] * 1e3) / 8000.0 if line else None
