@@ -814,19 +814,25 @@ int gbp_ba_set_stream(gbp_ba_t *h, void *hip_stream)
     return GBP_OK;
 }
 
+// A finish wave of the peer-store exchange that gave up waiting for a peer's partial sums leaves a mark; everything that hands results
+// to the caller (sync, beliefs, means, are / energy, checkpoints) looks at it first, so a timed-out sweep cannot pass for a result.
+// The mark stays until gbp_ba_sync has reported it.
+static int peer_check(gbp_ba *h, bool clear)
+{
+    if (!h->peer.connected || !h->peer.d_ctl) return GBP_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, h->peer.d_ctl + 1, sizeof(int), hipMemcpyDeviceToHost));
+    if (!err) return GBP_OK;
+    if (clear) HIPCHK(hipMemset(h->peer.d_ctl + 1, 0, sizeof(int)));
+    return fail(GBP_ESTATE, "peer-store exchange timed out: a rank's camera partial sums did not arrive (the camera beliefs since then are invalid)");
+}
+
 int gbp_ba_sync(gbp_ba_t *h)
 {
     ENTER(h);
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->peer.connected && h->peer.d_ctl) {              // a finish kernel gave up waiting for a peer's partial sums?
-        int err = 0;
-        HIPCHK(hipMemcpy(&err, h->peer.d_ctl + 1, sizeof(int), hipMemcpyDeviceToHost));
-        if (err) {
-            HIPCHK(hipMemset(h->peer.d_ctl + 1, 0, sizeof(int)));
-            return fail(GBP_ESTATE, "peer-store exchange timed out: a rank's camera partial sums did not arrive (the camera beliefs since then are invalid)");
-        }
-    }
-    return GBP_OK;
+    return peer_check(h, true);
 }
 
 // ------------------------------------------------------------------------------- priors ---
@@ -1332,6 +1338,7 @@ int gbp_ba_update_beliefs_sharded(gbp_ba_t *h)
 int gbp_ba_residual_sums(gbp_ba_t *h, double out[2])
 {
     ENTER(h);
+    CHK(peer_check(h, false));
     if (!out) return fail(GBP_EINVAL, "null argument");
     const Params &p = h->p;
     out[0] = out[1] = 0.0;
@@ -1400,6 +1407,7 @@ static int get_var_info(gbp_ba *h, const double *d_cam, int cam_stride, const do
 int gbp_ba_get_beliefs(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk_eta, double *lmk_lam)
 {
     ENTER(h);
+    CHK(peer_check(h, false));
     const Params &p = h->p;
     const double *d_lmk = nullptr;
     if (lmk_eta || lmk_lam) {
@@ -1423,6 +1431,7 @@ int gbp_ba_get_priors(gbp_ba_t *h, double *cam_eta, double *cam_lam, double *lmk
 int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
 {
     ENTER(h);
+    CHK(peer_check(h, false));
     const Params &p = h->p;
     if (cam_mu) {
         std::vector<double> cb;
@@ -1440,6 +1449,7 @@ int gbp_ba_get_means(gbp_ba_t *h, double *cam_mu, double *lmk_mu)
 int gbp_ba_get_covariances(gbp_ba_t *h, double *cam_sigma, double *lmk_sigma)
 {
     ENTER(h);
+    CHK(peer_check(h, false));
     const Params &p = h->p;
     if (!h->has_beliefs) return fail(GBP_ESTATE, "beliefs have not been computed yet (Sigma is zeros in the reference, gbp.py:166)");
     const size_t nc = (size_t)p.C * 21, nl = (size_t)p.L * 6;
@@ -1616,6 +1626,7 @@ int gbp_ba_fill_iters_since_relin(gbp_ba_t *h, int32_t value)
 int gbp_ba_means_snapshot(gbp_ba_t *h)
 {
     ENTER(h);
+    CHK(peer_check(h, false));
     const Params &p = h->p;
     const size_t n = (size_t)p.C * 6 + (size_t)p.L * 3;
     if (!h->copy_stream) {
@@ -1745,6 +1756,7 @@ int gbp_ba_state_size(gbp_ba_t *h, uint64_t *bytes)
 int gbp_ba_save_state(gbp_ba_t *h, void *buf, uint64_t bytes)
 {
     ENTER(h);
+    CHK(peer_check(h, false));
     uint64_t need = 0;
     CHK(gbp_ba_state_size(h, &need));
     if (!buf || bytes < need) return fail(GBP_EINVAL, "state buffer too small: %llu < %llu bytes", (unsigned long long)bytes, (unsigned long long)need);

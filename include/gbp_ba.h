@@ -174,7 +174,9 @@ int gbp_ba_comm_destroy(gbp_ba_t *h);
  *     and pass them to connect.  All ranks must have connected before the first sharded call (barrier on the side channel).
  *     GBP_PEER_RENDEZVOUS keeps the function set with gbp_ba_set_exchange as a hook called with (NULL, NULL, 0, stream) between
  *     the stores and the finish, which then stay two launches (logical ranks on ONE device must not spin on each other).  A
- *     finish wave gives up after GBP_PEER_TIMEOUT_MS (default 20000) and gbp_ba_sync then returns GBP_ESTATE. */
+ *     finish wave gives up after GBP_PEER_TIMEOUT_MS (default 20000); from then on everything that hands results to the caller
+ *     (get_beliefs / get_means / get_covariances, are / energy, means_snapshot, save_state) returns GBP_ESTATE until gbp_ba_sync has
+ *     reported it (and cleared the mark). */
 #define GBP_PEER_HANDLE_BYTES 64
 #define GBP_PEER_SAME_PROCESS 1
 #define GBP_PEER_RENDEZVOUS 2

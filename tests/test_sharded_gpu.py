@@ -312,6 +312,10 @@ def test_peer_exchange_times_out_instead_of_hanging(monkeypatch):
     b.peer_connect(1, handles, same_process=True)
     a.generate_priors_var(50.0)
     a.update_beliefs_sharded()                                # rank 1 never runs: its rows never arrive
+    for read_back in (a.beliefs, a.are, a.means):             # nothing hands out the invalid camera beliefs meanwhile
+        with pytest.raises(GbpError) as ei:
+            read_back()
+        assert ei.value.code == -5 and 'timed out' in str(ei.value)
     with pytest.raises(GbpError) as ei:
         a.sync()
     assert ei.value.code == -5 and 'timed out' in str(ei.value)
