@@ -89,6 +89,8 @@ struct FusedArgs {
     unsigned long long *clk;    // instrumented runs (gbp_ba_set_kernel_timing): where workgroup 0 stores the device's constant-rate clock
                                 // (wall_clock64) when it starts, or NULL.  HIP events around a launch also time the dispatch after the
                                 // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
+    int pin;                    // the first `pin` tiles of every workgroup's range use the memory-side cache as `nt` says; the rest stream
+                                // PAST it altogether, loads and message stores (fused_plan: graphs beyond the cache size)
 };
 
 // Instrumented launches: workgroup 0 stores the clock when it starts (a grid starts first -> last within ~0.5 us).  One plain store:
@@ -131,6 +133,17 @@ GBP_DEV void st2(double *__restrict__ base, unsigned byte_off, double x, double 
     *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + byte_off) = make_double2(x, y);
 }
 GBP_DEV void st1(double *__restrict__ base, unsigned byte_off, double x) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off) = x; }
+GBP_DEV void st2_nt(double *__restrict__ base, unsigned byte_off, double x, double y)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d v; v.x = x; v.y = y;
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(reinterpret_cast<char *>(base) + byte_off));
+}
+// (nts is wave-uniform: a scalar branch)
+GBP_DEV void st2x(double *__restrict__ base, unsigned byte_off, double x, double y, bool nts)
+{
+    if (nts) st2_nt(base, byte_off, x, y); else st2(base, byte_off, x, y);
+}
 
 // everything a tile's factors stream: six + five row pairs of the tile's block (16 bytes per lane each), the meta and state words
 struct TileStreams {
@@ -147,8 +160,8 @@ GBP_DEV double2 ld2_nt(const double *__restrict__ base, unsigned byte_off)
 
 // nt: bit 0 = the lin rows (x0 | z | variance) stream PAST the memory-side cache, bit 1 = the message rows too (nontemporal loads:
 // no allocation in the 256 MiB Infinity Cache).  The fused sweep of a graph whose whole working set fits that cache uses neither (at the
-// headline size bypassing it costs +12...18 us); a larger graph sends past it what does not fit, so that the rest STAYS resident from
-// sweep to sweep instead of everything thrashing (fused_launch picks the bits from the sizes); the general sweep sends both past it
+// headline size bypassing it costs +12...18 us); a larger graph sends the tiles that do not fit past it, loads and stores, so that the
+// rest STAYS resident from sweep to sweep instead of everything thrashing (FusedArgs::pin, fused_plan); the general sweep sends both past it
 // so that the cache keeps the staged camera rows for k_cam_partial_staged (126 against 132 us per sweep at 1M factors).
 template <int LOSS, bool STAGED>
 GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int nt)
@@ -180,7 +193,7 @@ GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int
 // the persistent loop, the late landmark beliefs, the addressing -- is shared with the fused sweep.  (Rounds 1-3 ran the general sweep
 // as one wave per tile, k_factor_tile: 107 us at 1M factors; that kernel now serves the stage-wise calls and the dense remainder.)
 constexpr int STAGED_WAVE_DOUBLES = WAVE_LDS_DOUBLES + WTILE * CSTAGE_PLAIN + WTILE / 2;      // messages | rows | cpos
-template <int LOSS, int NWAVES, bool STAGED = false>
+template <int LOSS, int NWAVES, bool STAGED = false, bool PINNED = false>      // PINNED: FusedArgs::pin is in force (graphs beyond the memory-side cache)
 __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -237,7 +250,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // everything the factor streams
         // (unconditional: the slots of a tile exist in storage for all 64 lanes, and straight-line loads need no merge
         //  copies that would make the wave wait for them before the tail below)
-        issue_streams<LOSS, STAGED>(p, t, lane, S, a.nt);
+        const bool past = PINNED && (t - tb) >= a.pin;       // this tile streams past the memory-side cache (FusedArgs::pin)
+        issue_streams<LOSS, STAGED>(p, t, lane, S, past ? 3 : a.nt);
         const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
         const unsigned long long words = (unsigned long long)__double_as_longlong(S.a[5].y);      // meta (low) | state (high): gbp_kernels.hpp ROW_SM
@@ -337,11 +351,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             wave_lds_sync();
             st2(msg_w, 2048u + lo, WC[0], WC[1]); st1(msg_w, 3072u + lo, WC[2]);
 #else
-            st2(msg_w, lo, qC[0], qC[1]); st2(msg_w, 1024u + lo, qL[0], qL[1]);
+            st2x(msg_w, lo, qC[0], qC[1], past); st2x(msg_w, 1024u + lo, qL[0], qL[1], past);
             wave_lds_sync();                               // every lane of the tile has read its landmark head
 #pragma unroll
             for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
-            st2(msg_w, 2048u + lo, WC[0], WC[1]); st2(msg_w, 3072u + lo, WC[2], VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
+            st2x(msg_w, 2048u + lo, WC[0], WC[1], past); st2x(msg_w, 3072u + lo, WC[2], VL[0], past); st2x(msg_w, 4096u + lo, VL[1], VL[2], past);
 #pragma unroll
             for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
 #endif
@@ -591,23 +605,30 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
 #endif
     pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, 0, env_dbg ? atoi(env_dbg) : 0, d_phase, nullptr};
     {
-        // What a sweep touches, against the 256 MiB memory-side cache.  Everything fits: nothing bypasses it.  Beyond it the lin rows
-        // (read-only in steady sweeps, 96 B per slot) go past it, so that the message rows and the records stay resident instead of
-        // everything thrashing: 94 against 99 us per sweep at 1.2M factors, 115 against 124 at 1.5M, neutral from 2M on, and WORSE
-        // below the cache size (88 against 82 us at 1.1M; at 1M 81 against 69): profiles/r04_size_sweep.jsonl.  Bypassing the message
-        // rows as well (bit 1) never paid.
+        // What a sweep touches, against the 256 MiB memory-side cache.  Everything fits: nothing bypasses it.  Beyond it the first
+        // tiles of every workgroup's range -- 160 MiB worth, tables and records included -- keep using the cache and stay resident
+        // from sweep to sweep; the remaining tiles stream PAST it, loads and message stores (nontemporal), instead of everything
+        // thrashing: 72.8 against 78.0 ps per factor at 1.35M factors, 72.8 / 75.8 at 2M, 68.5 / 69.2 at 10M against the round's
+        // earlier policy (lin rows of ALL tiles past the cache, bit 0 of nt, which had brought 1.2M-1.5M from 83 to 76-78), and
+        // WORSE below the cache size (71.3 against 67.3 at 1.1M): profiles/r04_size_sweep.jsonl, EXPERIMENTS.md.  The split is
+        // per workgroup so that all of them finish together.
         const double S = (double)p.T * WTILE, MiB = 1024.0 * 1024.0;
-        const double touched = S * (LIN_ROWS + MSG_ROWS) * 8 + S * 8 + (double)p.L * LREC * 8 + (double)pl.n_blocks * p.C * TROW * 8 +
-                               (double)p.C * (CAMREC + CBEL + 27) * 8;
-        int nt = touched > 256.0 * MiB ? 1 : 0;
-        if (const char *e = getenv("GBP_FUSED_NT")) nt = atoi(e);
-        pl.args.nt = nt;
+        const double fixed = (double)pl.n_blocks * p.C * TROW * 8 + (double)p.C * (CAMREC + CBEL + 27) * 8;
+        const double touched = S * (LIN_ROWS + MSG_ROWS) * 8 + S * 8 + (double)p.L * LREC * 8 + fixed;
+        const double per_tile = WTILE * (LIN_ROWS + MSG_ROWS) * 8.0 + (double)p.L * LREC * 8 / std::max(p.T, 1);
+        double keep_mib = touched > 256.0 * MiB ? 160.0 : -1.0;      // < 0: everything stays cacheable
+        if (const char *e = getenv("GBP_FUSED_PIN_MIB")) keep_mib = atof(e);
+        pl.args.nt = 0;
+        pl.args.pin = 0x7fffffff;
+        if (keep_mib >= 0.0) pl.args.pin = (int)(std::max(0.0, keep_mib * MiB - fixed) / per_tile / pl.n_blocks);
+        if (const char *e = getenv("GBP_FUSED_NT")) pl.args.nt = atoi(e);      // experiments: bit 0 lin rows, bit 1 message rows of the cacheable tiles
     }
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
                             (int)shmem) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
+    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true>))
 #undef GBP_SET_SHMEM
     pl.enabled = true;
     return 0;
@@ -624,10 +645,13 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     p.robustify = robustify; p.local_relin = local_relin;
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
     if (e0) (void)hipEventRecord(e0, stream);
-    switch (p.loss) {
+    switch (p.loss + (pl.args.pin != 0x7fffffff ? 4 : 0)) {
     case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 2: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 4: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 5: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
