@@ -52,6 +52,31 @@ def test_sparse_graphs_take_the_staged_sweep(oracle_mod, monkeypatch):
     assert e.info()['cam_groups'] == 1 and gap < BELIEF_TOL, (e.info(), gap)
 
 
+def test_tiles_past_the_memory_side_cache_change_nothing(monkeypatch):
+    """Graphs beyond the 256 MiB memory-side cache run the pinned variant of the fused sweep (FusedArgs::pin: the first tiles of a
+    workgroup keep using the cache, the rest stream past it with nontemporal loads and stores).  Cache hints only: forced on a
+    small graph -- every tile streamed, half of them, none -- the beliefs must be bitwise those of the plain kernel."""
+    from gbp_amd.engine import BAEngine
+    prob = make_synthetic(n_cams=40, n_lmks=60_000, obs_per_lmk=6, seed=8)          # 360k factors: ~24 tiles per workgroup
+    out = {}
+    for keep in (None, '0', '60', '100000'):
+        if keep is None:
+            monkeypatch.delenv('GBP_FUSED_PIN_MIB', raising=False)
+        else:
+            monkeypatch.setenv('GBP_FUSED_PIN_MIB', keep)
+        e = BAEngine.from_problem(prob)
+        assert e.info()['cam_groups'] == 1
+        e.generate_priors_var(50.0)
+        e.update_all_beliefs()
+        e.set_iters_since_relin(8)                      # so that sweeps relinearise (x0 stores) as well
+        e.iterate(12)
+        out[keep] = [a.copy() for a in e.beliefs()] + [e.relin_state()['iters_since_relin'].copy()]
+        e.close()
+    for keep in ('0', '60', '100000'):
+        for a, b in zip(out[keep], out[None]):
+            assert np.array_equal(a, b), keep
+
+
 def with_landmarks(p, degrees, seed=5):
     """p plus one landmark per entry of `degrees`, seen by that many cameras (points near the origin are in front of
     and inside the image of every camera of the generator's shell)."""
