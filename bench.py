@@ -561,7 +561,8 @@ def main():
                      "reduce start, the interval rocprofv3 reports as the kernel's duration (consecutive kernels tile the stream's timeline)")
         elif m['ev_ms'].size:                                    # general sweep: HIP events only
             ev_steady = pic['steady'][pic['ev_idx']] if pic['n'] else np.ones(m['ev_ms'].size, bool)
-            ev = m['ev_ms'][ev_steady] if ev_steady.any() else m['ev_ms']
+            ev_all = m['ev_ms'][:ev_steady.size]           # (more timed launches than stamped sweeps: the stamp ring holds 4096)
+            ev = ev_all[ev_steady] if ev_steady.any() else ev_all
             k_steady, k_med, k_min, n_steady = float(ev.mean()), float(np.median(ev)), float(ev.min()), int(ev.size)
             k_src = f"HIP events around every {EVENT_EVERY}-th launch, one extra replay of the batch"
         else:
@@ -589,7 +590,7 @@ def main():
         if m['ev_ms'].size and pic['n'] and fused:
             ev_steady = pic['steady'][pic['ev_idx']]
             if ev_steady.any():
-                roof["kernel_event_ms"] = float(m['ev_ms'][ev_steady].mean())
+                roof["kernel_event_ms"] = float(m['ev_ms'][:ev_steady.size][ev_steady].mean())
                 roof["kernel_event_note"] = (f"HIP events around every {EVENT_EVERY}-th launch of the same replay: includes the dispatch latency behind the "
                                              "event's barrier packet, reported as a cross-check only")
         if not traffic and traffic_src:
