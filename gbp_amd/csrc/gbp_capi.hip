@@ -390,7 +390,17 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
             if (rc != 0) return fail(GBP_EHIP, "general sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
         if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
-        if (h->p.C) hipLaunchKernelGGL(k_cam_partial_staged, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial, finish);
+        if (h->p.C) {
+            // One workgroup per camera.  Short runs (a camera with a few hundred factors: graphs with thousands of cameras) leave most
+            // of a 256-thread block idle through its reduction and 6x6 solve: 128 threads do 1M factors x 2 000 / 3 000 cameras in
+            // 125.6 / 127.4 us per sweep against 134.5 / 143.7, 3M factors x 13 682 cameras in 439 against 509; from ~700 factors per
+            // camera on the two are equal, at 2 000 per camera 256 threads win (122.9 against 128.0).  The block size fixes the order of
+            // the sums, so it depends on the graph's shape alone (GBP_CAM_BLOCK overrides, experiments).
+            static const int forced = getenv("GBP_CAM_BLOCK") ? atoi(getenv("GBP_CAM_BLOCK")) : 0;
+            const int cam_block = forced ? forced : ((long long)h->p.F < 640LL * h->p.C ? 128 : BLOCK);
+            if (cam_block == 128) hipLaunchKernelGGL(k_cam_partial_staged<128>, dim3(h->p.C), dim3(128), 0, h->stream, h->p, partial, finish);
+            else hipLaunchKernelGGL(k_cam_partial_staged<BLOCK>, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial, finish);
+        }
         HIPCHK(hipGetLastError());
         if (peer) CHK(launch_peer_push(h, partial, *peer));
         if (finished) *finished = finish != 0 && h->p.C > 0;

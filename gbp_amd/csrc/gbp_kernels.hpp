@@ -603,16 +603,17 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 // (shuffle tree, then the four waves) -- bitwise reproducible.
 // finish != 0 (single GPU: nothing to exchange): the camera belief is completed here -- prior + sum, 6x6 solve (gbp.py:182-193) --
 // instead of in a dependent k_cam_finish launch.
-__global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *__restrict__ partial, int finish)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__restrict__ partial, int finish)
 {
-    __shared__ double red[BLOCK / 64][27];
+    __shared__ double red[NT / 64][27];
     __shared__ double tot[27];
     const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
     const int e1 = p.cptr[c + 1];
-    for (int e = p.cptr[c] + threadIdx.x; e < e1; e += BLOCK) {
+    for (int e = p.cptr[c] + threadIdx.x; e < e1; e += NT) {
         const double2 *row = reinterpret_cast<const double2 *>(p.cstage + (size_t)e * p.crow);
         double v[CSTAGE_ROW];
 #pragma unroll
@@ -650,14 +651,14 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial_staged(Params p, double *
     if (threadIdx.x < 27) {
         double s2 = red[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < BLOCK / 64; ++w) s2 += red[w][threadIdx.x];
+        for (int w = 1; w < NT / 64; ++w) s2 += red[w][threadIdx.x];
         partial[(size_t)c * 27 + threadIdx.x] = s2;
         tot[threadIdx.x] = s2 + p.cprior[(size_t)c * 27 + threadIdx.x];
     }
     if (!finish) return;
     __syncthreads();
     double *rec = p.cbel + (size_t)c * CAMREC;
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) p.cbelief[(size_t)c * CBEL + threadIdx.x - 64] = tot[threadIdx.x - 64];
+    if (threadIdx.x >= NT - 27) p.cbelief[(size_t)c * CBEL + threadIdx.x - (NT - 27)] = tot[threadIdx.x - (NT - 27)];
     if (threadIdx.x < 7) {
         double v[27];
 #pragma unroll
