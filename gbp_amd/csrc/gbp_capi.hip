@@ -89,6 +89,8 @@ struct gbp_ba {
     double *xtra_buf = nullptr;                  // the allocation behind p.xtra when it was made after create
     bool lazy_xtra = false, fused_suspended = false;
     int cstage_cap = 0;                          // doubles per row the staging buffer was allocated for (0: not allocated yet)
+    bool cstage_x0_ok = false;                   // the x0 halves of the staged rows are those of the factors' present linearisation points
+                                                 // (only the staged sweep keeps them so: it then rewrites them for relinearising tiles alone)
     long lazy_since = 0;                         // sweeps run since the remainder was switched on (it is checked for all-zero every 16)
     bool resid_ok = false; double resid[2] = {0.0, 0.0};     // ARE / energy sums of the CURRENT state (ba.py asks for both every sweep)
     // streaming means export (viewer): device staging, two pinned host mirrors, a copy stream
@@ -256,6 +258,7 @@ static int launch_factor_stage(gbp_ba *h, int robustify, int local_relin)
     p.robustify = robustify; p.local_relin = local_relin;
     if (!p.T) return GBP_OK;
     const int nb = (p.T + BLOCK / 64 - 1) / (BLOCK / 64);
+    h->cstage_x0_ok = false;                                // (this kernel's rows may be the wide ones: the next staged sweep writes whole rows)
     CHK(time_begin(h));
     if (p.xtra) {
         switch (p.loss) {
@@ -309,6 +312,7 @@ static int ensure_staging(gbp_ba *h)
     if (!h->p.cstage || h->cstage_cap < h->p.crow) {
         CHK(dev_alloc(h, &h->p.cstage, std::max<size_t>((size_t)h->p.F, 1) * h->p.crow));
         h->cstage_cap = h->p.crow;
+        h->cstage_x0_ok = false;
     }
     if (!h->big_lmks.empty() && !h->d_big) {
         CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
@@ -366,6 +370,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         static const bool no_rev = getenv("GBP_NO_REVERSE") != nullptr;
         const int reverse = no_rev ? 0 : (int)(h->walk_parity & 1u);
         h->walk_parity ^= 1u;
+        h->cstage_x0_ok = false;                            // (a fused sweep moves linearisation points without staging them)
         int rc = fused_launch(h->fused, h->p, robustify, local_relin, partial, h->stream, finish, e0, e1, defer_big, reverse, peer, h->clk_cur, merged);
         if (merged && peer && finished) *finished = true;
         if (rc != 0) return fail(GBP_EHIP, "fused sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -381,11 +386,13 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         CHK(ensure_staging(h));
         if (h->p.xtra || getenv("GBP_TILE_KERNEL")) {       // the dense remainder rides in k_factor_tile (one wave per tile)
             h->dominant = "k_factor_tile";
+            h->cstage_x0_ok = false;                        // (its rows may be the wide ones: the next staged sweep writes whole rows)
             CHK(launch_factor_stage(h, robustify, local_relin));
         } else {                                             // the persistent loop, staging instead of a camera table
             h->dominant = "k_sweep_staged";
             CHK(time_begin(h));
-            const int rc = staged_launch(h->p, robustify, local_relin, h->n_cus, h->p.reverse_walk, h->stream, nullptr);
+            const int rc = staged_launch(h->p, robustify, local_relin, h->n_cus, h->p.reverse_walk, h->stream, nullptr, h->cstage_x0_ok ? 0 : 1);
+            h->cstage_x0_ok = true;
             CHK(time_end(h));
             if (rc != 0) return fail(GBP_EHIP, "general sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
@@ -1839,6 +1846,7 @@ int gbp_ba_restore_snapshot(gbp_ba_t *h)
     h->pending_possible = true;                              // (the restored state words may carry pending relinearisations)
     h->walk_parity = h->snap_parity;
     h->p.clk = h->snap_clk; h->p.clk_inc = 0;
+    h->cstage_x0_ok = false;                                // (the staged rows are not part of a checkpoint)
     return GBP_OK;
 }
 
@@ -1876,6 +1884,7 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     h->pending_possible = true;                              // (the loaded state words may carry pending relinearisations)
     h->walk_parity = hd.walk_parity & 1u;
     h->p.clk = (int)(hd.relin_clock & CLK_MASK); h->p.clk_inc = 0;
+    h->cstage_x0_ok = false;
     return GBP_OK;
 }
 

@@ -91,6 +91,8 @@ struct FusedArgs {
                                 // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
     int pin;                    // the first `pin` tiles of every workgroup's range use the memory-side cache as `nt` says; the rest stream
                                 // PAST it altogether, loads and message stores (fused_plan: graphs beyond the cache size)
+    int full_rows;              // STAGED: write whole camera-message rows (the staged x0 halves cannot be trusted: first staged sweep after
+                                // create / restore / a sweep of another kind); else only tiles in which a factor relinearised do
 };
 
 // Instrumented launches: workgroup 0 stores the clock when it starts (a grid starts first -> last within ~0.5 us).  One plain store:
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         GBP_PH_NOWAIT(5);                                  // landmark records through LDS
 
         double MCn[21], eC[6];
+        int tile_relin = 0;                                // factors of this tile that relinearised (valid in its active lanes)
         if (active) {
             double MLn[6], eL[3], muL[3];
             const double *lhead = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LHEAD;     // intact until the messages go in below
@@ -336,7 +339,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
                                                             st1(lin_w, 4096u + lo, x[8]);
                                                         },
                                                         qC, qL, WC, VL, eC, eL, MCn, MLn);
-            n_relin += relin_in_wave(relin);
+            tile_relin = relin_in_wave(relin);
+            n_relin += tile_relin;
             GBP_PH_NOWAIT(6);                              // the maths
 #if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1        // (this half's share of the stores: q_L, V_L)
             st2(msg_w, 1024u + lo, qL[0], qL[1]);
@@ -375,9 +379,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
                 wpos[lane] = S.cpos;
             }
             wave_lds_sync();
-            const int g8 = lane >> 3, k2 = lane & 7;
-            for (int f = g8; f < nf; f += 8)
-                reinterpret_cast<double2 *>(p.cstage + (size_t)wpos[f] * CSTAGE_PLAIN)[k2] = reinterpret_cast<const double2 *>(wr + f * CSTAGE_PLAIN)[k2];
+            // x0 moves only when a factor relinearises: in every other tile the first 64 bytes of its rows (x0[0..7]) are already what
+            // the last sweep staged, and only the second half -- x0[8] | q_C | W | pad -- goes out: 64 instead of 128 bytes per factor
+            if (a.full_rows || __builtin_amdgcn_readfirstlane(tile_relin) != 0) {
+                const int g8 = lane >> 3, k2 = lane & 7;
+                for (int f = g8; f < nf; f += 8)
+                    reinterpret_cast<double2 *>(p.cstage + (size_t)wpos[f] * CSTAGE_PLAIN)[k2] = reinterpret_cast<const double2 *>(wr + f * CSTAGE_PLAIN)[k2];
+            } else {
+                const int g16 = lane >> 2, k2 = 4 + (lane & 3);
+                for (int f = g16; f < nf; f += 16)
+                    reinterpret_cast<double2 *>(p.cstage + (size_t)wpos[f] * CSTAGE_PLAIN)[k2] = reinterpret_cast<const double2 *>(wr + f * CSTAGE_PLAIN)[k2];
+            }
             wave_lds_sync();
             pend = true; q_l0 = l0; q_nl = nl;
             continue;
@@ -680,12 +692,12 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
 }
 
 // the general sweep's factor kernel: the persistent loop in its STAGED form (no table: any number of cameras)
-inline int staged_launch(const Params &p0, int robustify, int local_relin, int n_cus, int reverse, hipStream_t stream, unsigned long long *clk)
+inline int staged_launch(const Params &p0, int robustify, int local_relin, int n_cus, int reverse, hipStream_t stream, unsigned long long *clk, int full_rows)
 {
     Params p = p0;
     p.robustify = robustify; p.local_relin = local_relin;
     FusedArgs a{};
-    a.reverse = reverse; a.clk = clk;
+    a.reverse = reverse; a.clk = clk; a.full_rows = full_rows; a.pin = 0x7fffffff;
     const int n_blocks = std::max(1, std::min(p.T, n_cus));
     const size_t shmem = sizeof(double) * ((size_t)WAT_WAVES * STAGED_WAVE_DOUBLES + 1);
     static bool attr_set = false;
