@@ -357,13 +357,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             wave_lds_sync();
             st2(msg_w, 2048u + lo, WC[0], WC[1]); st1(msg_w, 3072u + lo, WC[2]);
 #else
-            st2x(msg_w, lo, qC[0], qC[1], past); st2x(msg_w, 1024u + lo, qL[0], qL[1], past);
-            wave_lds_sync();                               // every lane of the tile has read its landmark head
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
-            st2x(msg_w, 2048u + lo, WC[0], WC[1], past); st2x(msg_w, 3072u + lo, WC[2], VL[0], past); st2x(msg_w, 4096u + lo, VL[1], VL[2], past);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
+            // (one wave-uniform branch around the whole block: five branches, one per store, cost the pinned variant 2-3 us per sweep)
+#define GBP_MSG_STORES(ST)                                                                                            \
+            ST(msg_w, lo, qC[0], qC[1]); ST(msg_w, 1024u + lo, qL[0], qL[1]);                                         \
+            wave_lds_sync();                               /* every lane of the tile has read its landmark head */   \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];                                   \
+            ST(msg_w, 2048u + lo, WC[0], WC[1]); ST(msg_w, 3072u + lo, WC[2], VL[0]); ST(msg_w, 4096u + lo, VL[1], VL[2]); \
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
+            if (past) { GBP_MSG_STORES(st2_nt) } else { GBP_MSG_STORES(st2) }
+#undef GBP_MSG_STORES
 #endif
             if (st != (int)(words >> 32))                   // the state word (high half of ROW_SM): only a factor that did more than age has a new one
                 *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;
@@ -630,12 +632,15 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
         const double fixed = (double)pl.n_blocks * p.C * TROW * 8 + (double)p.C * (CAMREC + CBEL + 27) * 8;
         const double touched = S * (LIN_ROWS + MSG_ROWS) * 8 + S * 8 + (double)p.L * LREC * 8 + fixed;
         const double per_tile = WTILE * (LIN_ROWS + MSG_ROWS) * 8.0 + (double)p.L * LREC * 8 / std::max(p.T, 1);
-        double keep_mib = touched > 256.0 * MiB ? 160.0 : -1.0;      // < 0: everything stays cacheable
+        // (the share that pays shrinks with the distance from the cache size: 200 MiB just beyond it -- 67.1 against 70.7 ps per factor at
+        //  1.15M factors with 160 -- 140 from 1.5M factors on: 73.4 against 76.2 / 78.3 with 180 / 220)
+        double keep_mib = touched > 256.0 * MiB ? std::min(200.0, std::max(140.0, 460.0 - touched / MiB)) : -1.0;      // < 0: everything stays cacheable
         if (const char *e = getenv("GBP_FUSED_PIN_MIB")) keep_mib = atof(e);
         pl.args.nt = 0;
         pl.args.pin = 0x7fffffff;
         if (keep_mib >= 0.0) pl.args.pin = (int)(std::max(0.0, keep_mib * MiB - fixed) / per_tile / pl.n_blocks);
         if (const char *e = getenv("GBP_FUSED_NT")) pl.args.nt = atoi(e);      // experiments: bit 0 lin rows, bit 1 message rows of the cacheable tiles
+        if (getenv("GBP_PLAN_DEBUG")) fprintf(stderr, "[gbp] fused plan: T %d blocks %d touched %.1f MiB keep %.1f MiB pin %d tiles per workgroup\n", p.T, pl.n_blocks, touched / MiB, keep_mib, pl.args.pin);
     }
     pl.shmem = shmem;
 #define GBP_SET_SHMEM(K)                                                                                              \
