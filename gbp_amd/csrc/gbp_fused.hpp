@@ -76,6 +76,15 @@ constexpr int WAT_WAVES = GBP_WAT_WAVES;            // two waves per SIMD.  Roun
 constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][10] landmark heads (mean | covariance | rows), then [64][9] messages
 static_assert(TILE_LMKS * LHEAD <= WAVE_LDS_DOUBLES, "landmark heads of a tile must fit the wave scratch");
 
+// The GBP_FUSED_DBG ablation switches are compiled into the sweep only with -DGBP_FUSED_DBG_SWITCHES (tools/profile_round.sh builds that
+// copy of the library for its timing-only ablations): as run-time tests they put half a dozen scalar branches into every tile of the
+// product kernel.
+#ifdef GBP_FUSED_DBG_SWITCHES
+#define GBP_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define GBP_DBG(a, bit) 0
+#endif
+
 struct FusedArgs {
     double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes
     int acc_doubles;            // cameras of the group * 27
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         const int t = tb + (valid ? (a.reverse ? ntl - 1 - ti : ti) : 0);
         GBP_PH(0);                                         // ticket
         if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
-            if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
+            if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
             GBP_PH_NOWAIT(2);
             break;
         }
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // this tile streams past the memory-side cache: FusedArgs::pin; every tile of the general sweep (the cache is left to the staged
         // camera rows: nontemporal message stores as well as loads, 116.6-117.3 against 119.4-119.7 us per sweep with plain stores)
         const bool past = STAGED || (PINNED && (t - tb) >= a.pin);
-        issue_streams<LOSS, STAGED>(p, t, lane, S, past ? 3 : a.nt);
+        issue_streams<LOSS, STAGED>(p, t, lane, S, past ? 3 : (PINNED ? a.nt : 0));      // (FusedArgs::nt: experiments with the pinned variant only)
         const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
         const unsigned long long words = (unsigned long long)__double_as_longlong(S.a[5].y);      // meta (low) | state (high): gbp_kernels.hpp ROW_SM
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
 
         // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
 #if !(defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 2)
-        if (pend && !(a.dbg & 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
+        if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
 #endif
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(2);                                  // landmark beliefs of the previous tile (LDS)
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         const int cam = active ? (int)(meta >> META_LMK_BITS) : 0;
         GBP_PH(3);                                         // the streams (and meta) have arrived
         {
-            const unsigned co = (unsigned)((a.dbg & 8) ? (cam & 7) : cam) * (unsigned)(CAMREC * 8);      // (dbg 8: what would a cheap gather buy?)
+            const unsigned co = (unsigned)(GBP_DBG(a, 8) ? (cam & 7) : cam) * (unsigned)(CAMREC * 8);      // (dbg 8: what would a cheap gather buy?)
             double v[CAMHEAD];
 #pragma unroll
             for (int i = 0; i < CAMHEAD / 2; ++i) { const double2 t2 = ld2(p.cbel, co + 16u * i); v[2 * i] = t2.x; v[2 * i + 1] = t2.y; }
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         wave_lds_sync();
         GBP_PH_NOWAIT(7);                                  // stores issued
         // camera accumulation strictly in tile order
-        if (!(a.dbg & 1)) while (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ti) __builtin_amdgcn_s_sleep(2);
+        if (!GBP_DBG(a, 1)) while (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ti) __builtin_amdgcn_s_sleep(2);
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
@@ -410,9 +419,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
 #if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1
         for (int r = 0; r < 0; ++r) {
 #else
-        for (int r = 0; r <= ((a.dbg & 32) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
+        for (int r = 0; r <= (GBP_DBG(a, 32) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
 #endif
-            if (mine && rank == r && !(a.dbg & 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
+            if (mine && rank == r && !GBP_DBG(a, 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
                 double *dst = acc + cloc * 27;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) unsafeAtomicAdd(dst + k, eC[k]);

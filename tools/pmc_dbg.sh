@@ -2,6 +2,9 @@
 # FETCH_SIZE / WRITE_SIZE of the fused sweep under the GBP_FUSED_DBG ablation switches (one PMC pass per counter and switch).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+# (the switches exist only in a library built with -DGBP_FUSED_DBG_SWITCHES: a scratch copy)
+(cd gbp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=fast -DGBP_FUSED_DBG_SWITCHES -o "$ROOT/tools/libgbp_dbg.so" gbp_capi.hip gbp_lin_capi.hip gbp_sort.hip 2> /dev/null)
+export GBP_HIP_LIB="$ROOT/tools/libgbp_dbg.so"
 for dbg in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     GBP_FUSED_DBG=$dbg timeout 200 rocprofv3 --pmc $c -f csv -d gpurun_out/pmc_dbg${dbg}_$c -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

@@ -5,7 +5,7 @@
 #  2. separate PMC passes FETCH_SIZE / WRITE_SIZE (they do not fit one pass), 1M factors
 #  3. the same three at 10M factors (--lmks 1000000): state far beyond the 256 MiB Infinity Cache
 #  4. SQ occupancy / stall counters, one pass per group (each under timeout)
-#  5. GBP_FUSED_DBG ablations (timing only)
+#  5. GBP_FUSED_DBG ablations (timing only; a scratch build with -DGBP_FUSED_DBG_SWITCHES)
 #  6. the general sweep (--no-fused) kernel stats
 # tools/summarize_round.py condenses the CSVs into gpurun_out/prof_<tag>/summary/ ; copy those files to profiles/.
 set -u
@@ -29,9 +29,12 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU
   timeout 200 rocprofv3 --pmc $grp -f csv -d $OUT/sq_$i -o run -- $B --steps 6 --warmup 2 > $OUT/bench_sq_$i.log 2>&1
   echo "sq group $i ($grp) rc=$?"
 done
+# the ablation switches are compiled out of the product kernel (run-time tests cost it 1.5 us per sweep): a scratch copy of the library has them
+(cd gbp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=fast -DGBP_FUSED_DBG_SWITCHES -o "$ROOT/tools/libgbp_dbg.so" gbp_capi.hip gbp_lin_capi.hip gbp_sort.hip 2> /dev/null)
 for dbg in 0 1 4 5 8 12 14; do
-  GBP_FUSED_DBG=$dbg timeout 300 $B --steps 200 --warmup 20 > $OUT/bench_dbg$dbg.json 2> $OUT/bench_dbg$dbg.err
+  GBP_HIP_LIB="$ROOT/tools/libgbp_dbg.so" GBP_FUSED_DBG=$dbg timeout 300 $B --steps 200 --warmup 20 > $OUT/bench_dbg$dbg.json 2> $OUT/bench_dbg$dbg.err
 done
+rm -f "$ROOT/tools/libgbp_dbg.so"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_general -o run -- $B --steps 100 --warmup 10 --no-fused > $OUT/bench_stats_general.log 2>&1
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python tools/summarize_round.py $OUT $TAG
