@@ -204,7 +204,7 @@ GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int
 // the persistent loop, the late landmark beliefs, the addressing -- is shared with the fused sweep.  (Rounds 1-3 ran the general sweep
 // as one wave per tile, k_factor_tile: 107 us at 1M factors; that kernel now serves the stage-wise calls and the dense remainder.)
 constexpr int STAGED_WAVE_DOUBLES = WAVE_LDS_DOUBLES + WTILE * CSTAGE_PLAIN + WTILE / 2;      // messages | rows | cpos
-template <int LOSS, int NWAVES, bool STAGED = false, bool PINNED = false>      // PINNED: FusedArgs::pin is in force (graphs beyond the memory-side cache)
+template <int LOSS, int NWAVES, bool STAGED = false, bool PINNED = false, bool SINGLE = false>      // PINNED: FusedArgs::pin is in force (graphs beyond the memory-side cache); SINGLE: see the accumulation
 __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -419,9 +419,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
 #if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1
         for (int r = 0; r < 0; ++r) {
 #else
-        for (int r = 0; r <= (GBP_DBG(a, 32) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
+        // Lanes of a tile that hit the same camera add in rank (= lane) order.  Few of them: one round per rank, one lane per camera in
+        // every ds_add_f64.  Many (graphs with a few dozen cameras: fr1desk has 63, and up to eight factors of a tile on one of them):
+        // ALL lanes in one instruction -- the LDS atomic unit applies the lanes that share an address in ascending lane order, which IS
+        // the rank order, so the sums are bitwise those of the rounds (tests/test_edge_shapes_gpu.py pins that on every run) at
+        // 27 instead of 27 x (maxrank + 1) instructions: fr1desk_small 15.05 -> 12.35 us per sweep, fr1desk 16.17 -> 13.73.  With one or
+        // two duplicates per tile the rounds are faster (1M factors x 500 cameras: 74.3 against 75.2 us per step).
+        // The choice is per graph (a kernel variant, fused_plan: by the number of cameras): a per-tile test cost the headline 0.8 us per sweep.
+        for (int r = 0; r <= ((GBP_DBG(a, 32) || SINGLE) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
 #endif
-            if (mine && rank == r && !GBP_DBG(a, 2)) {       // one lane per camera in a round: ds_add_f64 is a plain RMW here
+            if (mine && (SINGLE || rank == r) && !GBP_DBG(a, 2)) {
                 double *dst = acc + cloc * 27;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) unsafeAtomicAdd(dst + k, eC[k]);
@@ -561,6 +568,7 @@ struct FusedPlan {
     int n_groups = 0, group_cams = 0;                // (one camera group: the whole table in LDS)
     int n_blocks = 0, n_big = 0;
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
+    int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
     size_t shmem = 0;
     FusedArgs args{};
     int *d_big = nullptr;
@@ -647,6 +655,8 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
         if (const char *e = getenv("GBP_FUSED_PIN_MIB")) keep_mib = atof(e);
         pl.args.nt = 0;
         pl.args.pin = 0x7fffffff;
+        // few cameras: many factors of a 60-factor tile share one (fr1desk: 63 cameras, up to eight) -- the SINGLE variant of the accumulation
+        pl.single = getenv("GBP_ACC_SINGLE") ? atoi(getenv("GBP_ACC_SINGLE")) : (p.C <= 350 ? 1 : 0);      // (1M factors: 66.1 against 75.1 us per step at 64 cameras, 68.0 / 72.4 at 128, 69.7 / 71.6 at 200, 72.7 / 73.4 at 300, equal at 400, 75.2 / 74.3 at 500)
         if (keep_mib >= 0.0) pl.args.pin = (int)(std::max(0.0, keep_mib * MiB - fixed) / per_tile / pl.n_blocks);
         if (const char *e = getenv("GBP_FUSED_NT")) pl.args.nt = atoi(e);      // experiments: bit 0 lin rows, bit 1 message rows of the cacheable tiles
         if (getenv("GBP_PLAN_DEBUG")) fprintf(stderr, "[gbp] fused plan: T %d blocks %d touched %.1f MiB keep %.1f MiB pin %d tiles per workgroup\n", p.T, pl.n_blocks, touched / MiB, keep_mib, pl.args.pin);
@@ -657,6 +667,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
                             (int)shmem) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true>))
+    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true>))
 #undef GBP_SET_SHMEM
     pl.enabled = true;
     return 0;
@@ -673,13 +684,17 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     p.robustify = robustify; p.local_relin = local_relin;
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
     if (e0) (void)hipEventRecord(e0, stream);
-    switch (p.loss + (pl.args.pin != 0x7fffffff ? 4 : 0)) {
+    const bool pinned = pl.args.pin != 0x7fffffff;
+    switch (p.loss + (pinned ? 4 : (pl.single ? 8 : 0))) {
     case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 2: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 4: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 5: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 6: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 8: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 9: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);

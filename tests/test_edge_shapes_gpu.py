@@ -77,6 +77,37 @@ def test_tiles_past_the_memory_side_cache_change_nothing(monkeypatch):
             assert np.array_equal(a, b), keep
 
 
+def test_same_camera_lanes_in_one_atomic_instruction(monkeypatch):
+    """Factors of a tile that hit the same camera must add to its LDS row in rank (= lane) order.  With many of them per tile (few
+    cameras) the sweep issues ONE ds_add_f64 per entry for all lanes and relies on the LDS atomic unit applying same-address lanes in
+    ascending lane order; with few it runs one round per rank.  Both must give the same bits -- this test is what pins that hardware
+    behaviour: rounds (GBP_ACC_SINGLE=0), one instruction (=1) and the default (by the number of cameras) on the reference's own files
+    and on a 20-camera synthetic graph."""
+    import os
+    from conftest import DATA
+    from gbp_amd.balio import read_bal
+    from gbp_amd.engine import BAEngine
+    probs = [read_bal(os.path.join(DATA, 'fr1desk_small.txt')), read_bal(os.path.join(DATA, 'fr1desk.txt')),
+             make_synthetic(n_cams=20, n_lmks=6000, obs_per_lmk=8, seed=3)]
+    for prob in probs:
+        out = {}
+        for mode in ('0', '1', None):
+            if mode is None:
+                monkeypatch.delenv('GBP_ACC_SINGLE', raising=False)
+            else:
+                monkeypatch.setenv('GBP_ACC_SINGLE', mode)
+            e = BAEngine.from_problem(prob)
+            assert e.info()['cam_groups'] == 1
+            e.generate_priors_var(50.0)
+            e.update_all_beliefs()
+            e.set_iters_since_relin(8)
+            e.iterate(16)
+            out[mode] = [a.copy() for a in e.beliefs()]
+            e.close()
+        for mode in ('1', None):
+            assert all(np.array_equal(a, b) for a, b in zip(out[mode], out['0'])), mode
+
+
 def with_landmarks(p, degrees, seed=5):
     """p plus one landmark per entry of `degrees`, seen by that many cameras (points near the origin are in front of
     and inside the image of every camera of the generator's shell)."""
