@@ -24,7 +24,7 @@ import numpy as np
 from gbp_amd import _capi
 from gbp_amd.engine import BAEngine
 from gbp_amd.synthetic import make_synthetic
-p = make_synthetic(n_cams=500, n_lmks=int(os.environ.get('LMKS', 100_000)), obs_per_lmk=10, seed=0)
+p = make_synthetic(n_cams=int(os.environ.get('CAMS', 500)), n_lmks=int(os.environ.get('LMKS', 100_000)), obs_per_lmk=int(os.environ.get('OBS', 10)), seed=0)
 e = BAEngine.from_problem(p)
 e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(60); e.sync()
 nr, nc = ct.c_int32(), ct.c_int32()
