@@ -655,9 +655,9 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
         if (const char *e = getenv("GBP_FUSED_PIN_MIB")) keep_mib = atof(e);
         pl.args.nt = 0;
         pl.args.pin = 0x7fffffff;
-        // few cameras: many factors of a 60-factor tile share one (fr1desk: 63 cameras, up to eight) -- the SINGLE variant of the accumulation
-        pl.single = getenv("GBP_ACC_SINGLE") ? atoi(getenv("GBP_ACC_SINGLE")) : (p.C <= 350 ? 1 : 0);      // (1M factors: 66.1 against 75.1 us per step at 64 cameras, 68.0 / 72.4 at 128, 69.7 / 71.6 at 200, 72.7 / 73.4 at 300, equal at 400, 75.2 / 74.3 at 500)
         if (keep_mib >= 0.0) pl.args.pin = (int)(std::max(0.0, keep_mib * MiB - fixed) / per_tile / pl.n_blocks);
+        // few cameras: many factors of a 60-factor tile share one (fr1desk: 63 cameras, up to eight) -- the SINGLE variant of the accumulation
+        pl.single = getenv("GBP_ACC_SINGLE") ? atoi(getenv("GBP_ACC_SINGLE")) : (p.C <= (pl.args.pin != 0x7fffffff ? 200 : 350) ? 1 : 0);      // (1M factors: 66.1 against 75.1 us per step at 64 cameras, 68.0 / 72.4 at 128, 69.7 / 71.6 at 200, 72.7 / 73.4 at 300, equal at 400, 75.2 / 74.3 at 500; beyond the cache size -- the pinned variant -- 2M factors: 135.4 / 148.3 at 100 cameras, 151.0 / 143.7 at 300)
         if (const char *e = getenv("GBP_FUSED_NT")) pl.args.nt = atoi(e);      // experiments: bit 0 lin rows, bit 1 message rows of the cacheable tiles
         if (getenv("GBP_PLAN_DEBUG")) fprintf(stderr, "[gbp] fused plan: T %d blocks %d touched %.1f MiB keep %.1f MiB pin %d tiles per workgroup\n", p.T, pl.n_blocks, touched / MiB, keep_mib, pl.args.pin);
     }
@@ -668,6 +668,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true>))
+    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, true>))
 #undef GBP_SET_SHMEM
     pl.enabled = true;
     return 0;
@@ -685,7 +686,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
     if (e0) (void)hipEventRecord(e0, stream);
     const bool pinned = pl.args.pin != 0x7fffffff;
-    switch (p.loss + (pinned ? 4 : (pl.single ? 8 : 0))) {
+    switch (p.loss + (pinned ? 4 : 0) + (pl.single ? 8 : 0)) {
     case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 2: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
@@ -694,7 +695,10 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     case 6: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 8: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 9: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 10: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 12: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 13: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
     if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
