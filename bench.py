@@ -29,7 +29,6 @@ bytes per launch from the rocprofv3 PMC passes committed under profiles/ (not me
 two-pass implementation is kept only as `survey_equivalent_*`: this engine does that work in fewer bytes.
 """
 import argparse
-import importlib
 import json
 import os
 import socket
@@ -185,7 +184,7 @@ def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_grap
 
     g = None
     try:
-        g = ShardedBA(problem, device=local_rank, fused=not args.no_fused, exchange='peer')
+        g = ShardedBA(problem, device=local_rank, fused=False if args.no_fused else None, exchange='peer')
         ok = g.exchange == 'peer'
     except Exception as e:                                     # noqa: BLE001
         print(f"[bench] peer-store exchange unavailable: {e}", file=sys.stderr)
@@ -286,17 +285,20 @@ def free_port():
     return port
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, script=None):
     """`python bench.py --gpus N` outside torchrun: become the launcher of N ranks of this very command line."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-port', str(free_port()), os.path.abspath(script or __file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
-def main():
+def main(shard_factory=None, script=None):
+    """shard_factory / script: NOT reachable from the command line.  tests/tools/bench_dry_launch.py -- test infrastructure, run in the
+    build container where there is no GPU -- passes a double for a rank's engine and its own path, so that the launch path (spawning
+    the ranks, rendezvous, the one JSON line) can be exercised without a device; such a line is marked "dry_run" and measures nothing."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -318,13 +320,10 @@ def main():
     ap.add_argument('--python-loop', action='store_true', help='N > 1: drive the sweeps from Python (shard_begin / all_gather / shard_end)')
     ap.add_argument('--dump-sweeps', default=None, help='write the per-sweep kernel times (ms) and relinearisation counts of the instrumented replay to this .npz')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend of the side channel (tests: gloo)')
-    ap.add_argument('--engine-factory', default=None,
-                    help='module:callable building a rank\'s engine double (launch-path tests in the build container; the result '
-                         'is then marked "dry_run" and is not a measurement)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        raise SystemExit(spawn_ranks(args.gpus))
+        raise SystemExit(spawn_ranks(args.gpus, script))
 
     # Only the JSON line may reach stdout: native libraries (RCCL prints a version banner at communicator creation) write to
     # file descriptor 1 directly, so the descriptor itself is pointed at stderr and the result goes out through a saved copy.
@@ -338,7 +337,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dry = args.engine_factory is not None
+    dry = shard_factory is not None
     side_dev = 'cpu' if (dry or args.backend == 'gloo') else 'cuda'      # where the side channel's few scalars live
     if os.environ.get('GBP_BENCH_SHARE_GPU'):                             # tests on a one-GPU box: every rank on device 0 (gloo + peer exchange)
         local_rank = 0
@@ -364,19 +363,17 @@ def main():
         import torch.distributed as dist
         from gbp_amd.sharded import ShardedBA
         if dry:
-            mod, fn = args.engine_factory.split(':')
-            sys.path.insert(0, os.path.join(REPO, 'tests'))
             dist.init_process_group(args.backend)
-            graph = ShardedBA(problem, engine_factory=getattr(importlib.import_module(mod), fn))
+            graph = ShardedBA(problem, engine_factory=shard_factory)
         else:
             if 'MASTER_ADDR' not in os.environ:                     # --sharded without torchrun: a one-rank group of our own
                 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
             dist.init_process_group(args.backend, **({} if args.backend == 'gloo' else {'device_id': torch.device('cuda', local_rank)}))
-            graph = ShardedBA(problem, device=local_rank, fused=not args.no_fused, library_loop=not args.python_loop,
+            graph = ShardedBA(problem, device=local_rank, fused=False if args.no_fused else None, library_loop=not args.python_loop,
                               always_exchange=args.sharded, exchange='peer' if args.exchange == 'peer' else 'rccl')
     else:
         from gbp_amd.engine import BAEngine
-        graph = BAEngine.from_problem(problem, device=local_rank, fused=not args.no_fused)
+        graph = BAEngine.from_problem(problem, device=local_rank, fused=False if args.no_fused else None)      # None: the library picks the sweep, as for any user
 
     def fence():
         if dist is not None:

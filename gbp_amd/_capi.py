@@ -14,9 +14,11 @@ _ip = ct.POINTER(ct.c_int32)
 _bp = ct.POINTER(ct.c_uint8)
 
 LOSS = {None: 0, 'None': 0, 'none': 0, 'huber': 1, 'constant': 2}
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_NO_FUSED = 1
 FLAG_DEVICE_INPUT = 2
+FLAG_FORCE_FUSED = 4
+PLAN_INFO_FIELDS = 8
 CAM_PARTIAL_DOUBLES = 27
 COMM_ID_BYTES = 128
 XCH_ALWAYS = 1
@@ -103,6 +105,7 @@ SIGNATURES = {
     'gbp_ba_comm_destroy': (ct.c_int, [ct.c_void_p]),
     'gbp_ba_peer_export': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_void_p, ct.c_int32]),
     'gbp_ba_peer_connect': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_void_p, ct.c_int32]),
+    'gbp_ba_peer_selftest': (ct.c_int, [ct.c_void_p, ct.c_int32]),
     'gbp_ba_iterate_sharded': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]),
     'gbp_ba_update_beliefs_sharded': (ct.c_int, [ct.c_void_p]),
     'gbp_ba_set_kernel_timing': (ct.c_int, [ct.c_void_p, ct.c_int32]),
@@ -126,7 +129,7 @@ SIGNATURES = {
     'gbp_lin_get_means': (ct.c_int, [ct.c_void_p, _dp]),
     'gbp_lin_get_messages': (ct.c_int, [ct.c_void_p, _dp, _dp, _dp, _dp]),
     'gbp_ba_fused_max_cams': (ct.c_int, []),
-    'gbp_ba_grouped_max_cams': (ct.c_int, []),
+    'gbp_ba_plan_info': (ct.c_int, [ct.c_void_p, _ip, ct.c_int32]),
     'gbp_ba_phase_profile': (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int32, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     'gbp_ba_check_layout': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32)]),
     'gbp_ba_info': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),

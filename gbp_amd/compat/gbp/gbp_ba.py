@@ -6,6 +6,8 @@ are lazy sequences of thin views over host mirrors of the device state, so scrip
 (ba.py:68-105, vis/ba_vis.py:35-55,105-115) run unchanged -- including per-factor writes to `iters_since_relin`.
 There is no CPU implementation behind this module: without a gfx950 device create_ba_graph raises.
 """
+from array import array
+
 import numpy as np
 
 from gbp_amd.balio import read_bal, reference_factor_order
@@ -118,8 +120,8 @@ class _VariableView:
 class _FactorViewBase(int):
     """Factor surface (gbp.py:201-249) of one reprojection factor (reference factor order).  A view IS its factor id (an int with no
     state of its own: everything lives in the graph), and `iters_since_relin` -- the one attribute ba.py touches on EVERY factor in
-    EVERY iteration (ba.py:91-93 writes, :96-99 reads) -- is a property whose getter and setter are the C-level `list.__getitem__` /
-    `list.__setitem__` of the graph's host mirror: no Python frame per factor.  The class is specialised per graph (_factor_view_class)."""
+    EVERY iteration (ba.py:91-93 writes, :96-99 reads) -- is a property whose getter and setter are the C-level `__getitem__` /
+    `__setitem__` of the graph's host mirror (an int32 array.array): no Python frame per factor.  The class is specialised per graph (_factor_view_class)."""
     __slots__ = ()
     _g = None
     dofs_conditional_vars = 9
@@ -201,13 +203,17 @@ def _factor_view_class(graph, mirror):
 
 
 class _FactorSeq:
-    """graph.factors: F stateless views over one host mirror.  Iterating (ba.py:92, :98) refreshes the mirror once -- 4 bytes per factor from
-    the device -- and then walks a list; whatever the loop wrote into `iters_since_relin` is found by comparing the mirror with the
+    """graph.factors: F stateless views over ONE host mirror of iters_since_relin (an int32 array.array: its C-level __getitem__ /
+    __setitem__ are the views' property, and numpy reads or overwrites all of it through the buffer protocol in about a millisecond per
+    million factors).  The mirror is kept current for as long as views may be around: the graph re-reads it after every device call
+    that can change it (BAFactorGraph._invalidate), so a view HELD across synchronous_iteration() reads the new value like the
+    reference's long-lived Factor objects do, and whatever was written through any view is found by comparing the mirror with the
     device's values before the next device call (BAFactorGraph._flush)."""
 
     def __init__(self, graph, n):
         self._g, self._n = graph, n
-        self._mirror = [0] * n
+        self._mirror = array('i', bytes(4 * n))
+        self._np = np.frombuffer(self._mirror, dtype=np.int32) if n else np.zeros(0, np.int32)      # the same memory, as numpy sees it
         self._cls = _factor_view_class(graph, self._mirror)
         self._views = None
 
@@ -222,14 +228,12 @@ class _FactorSeq:
         if not 0 <= i < self._n:
             raise IndexError(i)
         self._g._refresh_iters()
-        self._g._factors_touched = True
         return self._cls(i)
 
     def __iter__(self):
         self._g._refresh_iters()
         if self._views is None:
             self._views = list(map(self._cls, range(self._n)))
-        self._g._factors_touched = True
         return iter(self._views)
 
     def __add__(self, other):
@@ -262,21 +266,26 @@ class BAFactorGraph:
         self.n_var_nodes, self.n_factor_nodes, self.n_edges = self._C + self._L, self._F, 2 * self._F
         self._cache = {}
         self._iters_dev, self._iters_fresh = None, False  # iters_since_relin as last read from the device; is the factors' mirror current?
-        self._factors_touched = False                     # has a view been handed out since the mirror was last compared with the device?
+        self._views_out = False                           # has a factor view ever been handed out?  (then the mirror is kept current)
         self._priors_host = None                          # priors written from Python, waiting to go to the device
         self._adj = None
 
     # ---- host mirrors ------------------------------------------------------------------------------------------
-    def _invalidate(self):
+    def _invalidate(self, iters_changed=True):
+        """After a device call.  Once factor views are out the mirror of iters_since_relin is re-read at once (4 bytes per factor): a view
+        the caller still holds must show the device's value, and a write through it must not be lost to a later refresh."""
         self._cache.clear()
-        self._iters_fresh = False
+        if iters_changed:
+            self._iters_fresh = False
+            if self._views_out:
+                self._refresh_iters()
 
     def _refresh_iters(self):
         """graph.factors' mirror of iters_since_relin: one 4 F-byte read per device state, shared by every view"""
+        self._views_out = True
         if not self._iters_fresh:
-            self._flush()                                      # (writes of an earlier loop go to the device first)
             self._iters_dev = self._engine.iters_since_relin()
-            self.factors._mirror[:] = self._iters_dev.tolist()
+            self.factors._np[:] = self._iters_dev
             self._iters_fresh = True
 
     def _cached(self, key, fn):
@@ -323,16 +332,14 @@ class BAFactorGraph:
             self._engine.set_priors(*self._priors_host)
             self._priors_host = None
             self._cache.pop('pri', None)
-        if self._iters_fresh and self._factors_touched:        # a loop over graph.factors may have written iters_since_relin (ba.py:91-93)
-            self._factors_touched = False
-            it = np.array(self.factors._mirror, dtype=np.int64)
-            if not np.array_equal(it, self._iters_dev):
-                if np.all(it == it[0]):
-                    self._engine.set_iters_since_relin(int(it[0]))      # ba.py:91-93 writes the same value everywhere
-                else:
-                    self._engine.set_iters_since_relin(it.astype(np.int32))
-                self._iters_dev = it.astype(np.int32)
-                self._cache.pop('relin', None)
+        if self._iters_fresh and not np.array_equal(self.factors._np, self._iters_dev):      # written through a view (ba.py:91-93)
+            it = self.factors._np
+            if np.all(it == it[0]):
+                self._engine.set_iters_since_relin(int(it[0]))          # ba.py:91-93 writes the same value everywhere
+            else:
+                self._engine.set_iters_since_relin(it)
+            self._iters_dev = it.copy()
+            self._cache.pop('relin', None)
 
     def _adjacent(self, kind, i):
         if self._adj is None:
@@ -345,23 +352,23 @@ class BAFactorGraph:
     def generate_priors_var(self, weaker_factor=100):
         self._flush()
         self._engine.generate_priors_var(weaker_factor)
-        self._invalidate()
+        self._invalidate(iters_changed=False)
 
     def weaken_priors(self, weakening_factor):
         self._flush()                     # priors written through node.prior first, or the next flush would undo the weakening
         self._engine.weaken_priors(weakening_factor)
-        self._invalidate()
+        self._invalidate(iters_changed=False)
 
     def set_priors_var(self, priors):
         self._flush()
         self._engine.set_priors_var(priors)
-        self._invalidate()
+        self._invalidate(iters_changed=False)
 
     # ---- sweep (gbp.py:46-92) ----------------------------------------------------------------------------------
     def update_all_beliefs(self):
         self._flush()
         self._engine.update_all_beliefs()
-        self._invalidate()
+        self._invalidate(iters_changed=False)
 
     def synchronous_iteration(self, local_relin=True, robustify=False):
         self._flush()
@@ -380,7 +387,7 @@ class BAFactorGraph:
     def robustify_all_factors(self):
         self._flush()
         self._engine.robustify_all_factors()
-        self._invalidate()
+        self._invalidate(iters_changed=False)
 
     def relinearise_factors(self):
         self._flush()

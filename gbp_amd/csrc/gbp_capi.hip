@@ -84,6 +84,8 @@ struct gbp_ba {
     std::vector<void *> allocs;
     bool has_beliefs = false;
     int n_cus = 0;
+    bool staged_auto = false;                    // the general sweep was picked by the sparseness rule (build_graph), not asked for
+    bool staged_attr_set = false;                // k_sweep_staged's dynamic-LDS attribute has been set on this handle's device (staged_launch)
     bool pending_possible = false;               // a stage-wise relinearise / compute_factors has run since the messages were last computed
     // dense message remainder allocated on demand (a damped factor that moves its linearisation point: enable_remainder)
     double *xtra_buf = nullptr;                  // the allocation behind p.xtra when it was made after create
@@ -133,7 +135,8 @@ struct gbp_ba {
         int n_ranks = 0, rank = 0; bool connected = false;
         void *base[MAX_PEERS] = {}; bool opened[MAX_PEERS] = {};
         unsigned long long seq = 0;
-        int *d_ctl = nullptr;                    // {unused, err}: a finish wave that gave up waiting sets err
+        int *d_ctl = nullptr;                    // {unused, err, selftest code, selftest rank}: a finish wave that gave up waiting sets err
+        unsigned long long probe_seq = 0;        // self-tests run so far (every rank runs the same number)
         long long timeout_ticks = 0;
     } peer;
     hipStream_t side_stream = nullptr;           // beliefs of over-sized landmarks run beside the exchange
@@ -391,7 +394,7 @@ static int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_re
         } else {                                             // the persistent loop, staging instead of a camera table
             h->dominant = "k_sweep_staged";
             CHK(time_begin(h));
-            const int rc = staged_launch(h->p, robustify, local_relin, h->n_cus, h->p.reverse_walk, h->stream, nullptr, h->cstage_x0_ok ? 0 : 1);
+            const int rc = staged_launch(h->p, robustify, local_relin, h->n_cus, h->p.reverse_walk, h->stream, nullptr, h->cstage_x0_ok ? 0 : 1, &h->staged_attr_set);
             h->cstage_x0_ok = true;
             CHK(time_end(h));
             if (rc != 0) return fail(GBP_EHIP, "general sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -476,9 +479,10 @@ int rccl_exchange(void *ctx, const double *send_dev, double *recv_dev, uint64_t 
 }
 }  // namespace
 
-// mailbox geometry: [2 halves][n_ranks][C] rows of PEER_ROW doubles (27 sums | tag)
+// mailbox geometry: [2 halves][n_ranks][C] rows of PEER_ROW doubles (27 sums | tag), then [n_ranks] probe rows (gbp_ba_peer_selftest)
 static inline size_t peer_block(const gbp_ba *h) { return (size_t)std::max(h->p.C, 1) * PEER_ROW; }
-static inline size_t peer_bytes(const gbp_ba *h, int n) { return 2 * (size_t)n * peer_block(h) * sizeof(double); }
+static inline size_t peer_bytes(const gbp_ba *h, int n) { return (2 * (size_t)n * peer_block(h) + (size_t)n * PEER_ROW) * sizeof(double); }   // + the self-test's probe rows
+static inline double *peer_probe(const gbp_ba *h, void *base, int n, int src) { return static_cast<double *>(base) + 2 * (size_t)n * peer_block(h) + (size_t)src * PEER_ROW; }
 static inline double *peer_data(const gbp_ba *h, void *base, int n, int half, int src)
 {
     return static_cast<double *>(base) + ((size_t)half * n + src) * peer_block(h);
@@ -694,7 +698,8 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         double staged_below = 0.75;
         if (const char *e = getenv("GBP_STAGED_BELOW")) staged_below = atof(e);
         const bool sparse = (double)F < staged_below * (double)n_wg * (double)C;
-        if (sparse) h->flags |= GBP_FLAG_NO_FUSED;
+        h->staged_auto = sparse && !(h->flags & (GBP_FLAG_FORCE_FUSED | GBP_FLAG_NO_FUSED));
+        if (h->staged_auto) h->flags |= GBP_FLAG_NO_FUSED;
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
         const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0) + (p.loss != 0 ? 1 : 0)) * sizeof(double) + S * sizeof(int)
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
@@ -1205,10 +1210,10 @@ int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t fla
         pe.finegrained = true;
     }
     HIPCHK(hipMemsetAsync(pe.mailbox, 0, bytes, h->stream));
-    if (!pe.d_ctl) HIPCHK(hipMalloc(reinterpret_cast<void **>(&pe.d_ctl), 2 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(pe.d_ctl, 0, 2 * sizeof(int), h->stream));
+    if (!pe.d_ctl) HIPCHK(hipMalloc(reinterpret_cast<void **>(&pe.d_ctl), 4 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(pe.d_ctl, 0, 4 * sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    pe.n_ranks = n_ranks; pe.seq = 0;
+    pe.n_ranks = n_ranks; pe.seq = 0; pe.probe_seq = 0;
     std::memset(handle64, 0, GBP_PEER_HANDLE_BYTES);
     if (flags & GBP_PEER_SAME_PROCESS) {
         std::memcpy(handle64, &pe.mailbox, sizeof(void *));
@@ -1252,6 +1257,31 @@ int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *
     if (!(flags & GBP_PEER_RENDEZVOUS)) { h->xch_fn = nullptr; h->xch_ctx = nullptr; }
     h->xch_rank = rank; h->xch_ranks = n_ranks;
     pe.connected = true;
+    return GBP_OK;
+}
+
+// Every rank calls this after gbp_ba_peer_connect -- and after a side-channel barrier, so that every mailbox is mapped everywhere -- and
+// before the first sharded call: k_peer_selftest (gbp_kernels.hpp) sends one tagged row to every rank and checks the rows of all ranks.
+int gbp_ba_peer_selftest(gbp_ba_t *h, int32_t timeout_ms)
+{
+    ENTER(h);
+    gbp_ba::Peer &pe = h->peer;
+    if (!pe.connected) return fail(GBP_ESTATE, "peer exchange: self-test before gbp_ba_peer_connect");
+    const int n = pe.n_ranks;
+    PeerOut po{};
+    po.n = n; po.seq = 0x9b50000000000000ull | ++pe.probe_seq;
+    for (int r = 0; r < n; ++r) po.dst[r] = peer_probe(h, pe.base[r], n, pe.rank);
+    int clk_khz = 0;
+    if (hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || clk_khz <= 0) clk_khz = 100000;
+    const long long ticks = (long long)((double)std::max(1, timeout_ms) * (double)clk_khz);
+    HIPCHK(hipMemsetAsync(pe.d_ctl + 2, 0, 2 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(64), 0, h->stream, po, peer_probe(h, pe.mailbox, n, 0), pe.rank, ticks, pe.d_ctl + 2);
+    HIPCHK(hipGetLastError());
+    int res[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(res, pe.d_ctl + 2, sizeof res, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (res[0] & 2) return fail(GBP_ESTATE, "peer exchange self-test: the probe row of rank %d arrived in rank %d's mailbox with wrong contents", res[1], pe.rank);
+    if (res[0] & 1) return fail(GBP_ESTATE, "peer exchange self-test: the probe row of rank %d did not reach rank %d within %d ms", res[1], pe.rank, timeout_ms);
     return GBP_OK;
 }
 
@@ -1860,22 +1890,26 @@ int gbp_ba_load_state(gbp_ba_t *h, const void *buf, uint64_t bytes)
     StateHeader hd;
     std::memcpy(&hd, buf, sizeof hd);
     if (std::memcmp(hd.magic, "GBPSTATE", 8) != 0) return fail(GBP_EINVAL, "not a GBP state blob (magic)");
-    if (hd.version == 7 && hd.F == h->p.F && hd.T == h->p.T) {      // the blob decides whether the handle carries a remainder
-        if ((hd.reserved & 1u) && !h->p.xtra) CHK(enable_remainder(h));
-        if (!(hd.reserved & 1u) && h->p.xtra) {
-            if (!h->lazy_xtra) return fail(GBP_EINVAL, "the state blob has no dense message remainder but this graph always carries one (num_undamped_iters = 0)");
-            CHK(remainder_drop(h));
-        }
-    }
-    uint64_t need = 0;
-    CHK(gbp_ba_state_size(h, &need));
     if (hd.version != 7)            // 1-3: dense / core-only message layouts, 4: beliefs without covariances, 5: state / meta words in arrays of their own, 6: iters_since_relin stored instead of clock values
         return fail(GBP_EINVAL, "unsupported state blob version %u (this library reads and writes version 7; INTEGRATION.md)", hd.version);
     uint64_t mine = 0;
     CHK(graph_hash(h, &mine));
     if (hd.F != h->p.F || hd.T != h->p.T || hd.L != h->p.L || hd.C != h->p.C || hd.graph_hash != mine)
         return fail(GBP_EINVAL, "state blob belongs to a different graph (F/L/C or factor order differ)");
+    // Everything is validated BEFORE the handle is touched: the blob decides whether the handle carries a dense remainder, and a rejected
+    // blob must leave the handle as it was.
+    const bool blob_xtra = (hd.reserved & 1u) != 0;
+    if (!blob_xtra && h->p.xtra && !h->lazy_xtra)
+        return fail(GBP_EINVAL, "the state blob has no dense message remainder but this graph always carries one (num_undamped_iters = 0)");
+    uint64_t need = sizeof(StateHeader);
+    {
+        const std::vector<StatePart> parts = state_parts(h);                      // (the remainder is the last part)
+        for (size_t i = 0; i + 1 < parts.size(); ++i) need += parts[i].bytes;
+        if (blob_xtra) need += (size_t)h->p.T * WTILE * XTRA_ROW * sizeof(double);
+    }
     if (bytes < need || hd.payload_bytes != need - sizeof(StateHeader)) return fail(GBP_EINVAL, "state blob truncated");
+    if (blob_xtra && !h->p.xtra) CHK(enable_remainder(h));
+    if (!blob_xtra && h->p.xtra) CHK(remainder_drop(h));
     const char *in = static_cast<const char *>(buf) + sizeof hd;
     for (const StatePart &q : state_parts(h)) {
         if (q.bytes) HIPCHK(hipMemcpyAsync(q.dev, in, q.bytes, hipMemcpyHostToDevice, h->stream));
@@ -2072,9 +2106,16 @@ int gbp_ba_fused_max_cams(void)
     return fused_max_cams();
 }
 
-int gbp_ba_grouped_max_cams(void)
+int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n)
 {
-    return fused_max_cams();                                 // (no second camera group any more: the general sweep takes over above it)
+    if (!h || (n > 0 && !out)) return fail(GBP_EINVAL, "null argument");
+    const bool pinned = h->fused.enabled && h->fused.args.pin != 0x7fffffff;
+    const int32_t v[GBP_PLAN_INFO_FIELDS] = {
+        h->fused.enabled ? 1 : 0, h->staged_auto ? 1 : 0, h->fused.enabled ? h->fused.single : 0, h->fused.single_probe,
+        pinned ? h->fused.args.pin : -1, h->fused.enabled ? h->fused.n_blocks : std::max(1, std::min(h->p.T, h->n_cus)), h->p.T,
+        (int32_t)h->big_lmks.size()};
+    for (int i = 0; i < n && i < GBP_PLAN_INFO_FIELDS; ++i) out[i] = v[i];
+    return GBP_OK;
 }
 
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks)

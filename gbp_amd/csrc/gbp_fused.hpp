@@ -56,6 +56,7 @@
 #include "gbp_kernels.hpp"
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace gbp {
@@ -558,6 +559,77 @@ __global__ __launch_bounds__(XCHG_THREADS) void k_cam_reduce_xchg(Params p, cons
     for (int c = blockIdx.x + wave * gridDim.x; c < p.C; c += (XCHG_THREADS / 64) * gridDim.x) cam_finish_wave(p, nullptr, peer.n, 0, wait, c, lane);
 }
 
+
+// ---- the SINGLE accumulation's hardware assumption, checked where it is relied on ---------------------------------------------
+// SINGLE (k_sweep_wat<.., SINGLE = true>) lets every lane of a tile issue its ds_add_f64 in ONE instruction even when several lanes hit
+// the same table entry, and counts on the LDS atomic unit applying same-address lanes in ASCENDING LANE ORDER -- the order of the
+// rank rounds -- for sums that are bitwise those of the rounds variant (equal across ranks, run to run, and across the checkpoint
+// tests).  No ISA document promises that order; it is what gfx950 does (EXPERIMENTS.md round 4).  So the plan of every graph that would
+// select SINGLE first runs this probe on the device it will run on (once per device and process): one wave, seven address patterns
+// from "all 64 lanes on one entry" to "eight lanes each on eight entries", addends of wildly different magnitudes (so that any other
+// order rounds differently), compared bitwise with the same additions made one by one in lane order.  On a mismatch the plan falls
+// back to the rounds variant and says so (gbp_ba_plan_info).
+GBP_DEV int single_probe_addr(int lane, int pat)
+{
+    switch (pat) {
+    case 0: return 0;
+    case 1: return lane & 1;
+    case 2: return lane % 3;
+    case 3: return lane >> 3;
+    case 4: return (lane * 7) & 7;
+    case 5: return lane < 40 ? 0 : (lane & 7);
+    default: return (lane * lane + 3 * lane) & 7;
+    }
+}
+constexpr int SINGLE_PROBE_PATTERNS = 7;
+__global__ __launch_bounds__(64) void k_single_probe(int *out)
+{
+    __shared__ double acc[8], val[64];
+    const int lane = threadIdx.x;
+    int bad = 0;
+    for (int pat = 0; pat < SINGLE_PROBE_PATTERNS; ++pat) {
+        const unsigned hsh = ((unsigned)lane * 2654435761u + (unsigned)pat * 40503u) >> 7;
+        val[lane] = ldexp((double)(hsh & 0xfffffu) + 0.5, (int)((lane * 13 + pat * 7) % 41) - 20) * ((hsh >> 21) & 1u ? -1.0 : 1.0);
+        if (lane < 8) acc[lane] = 0.1 * (lane + 1);
+        __syncthreads();
+        unsafeAtomicAdd(&acc[single_probe_addr(lane, pat)], val[lane]);      // the sweep's instruction: ds_add_f64, all lanes at once
+        __syncthreads();
+        if (lane < 8) {
+            double e = 0.1 * (lane + 1);
+            for (int l = 0; l < 64; ++l)
+                if (single_probe_addr(l, pat) == lane) e += val[l];          // (val[] is already rounded: nothing to contract)
+            if (__double_as_longlong(e) != __double_as_longlong(acc[lane])) bad |= 1 << pat;
+        }
+        __syncthreads();
+    }
+    if (bad) atomicOr(out, bad);
+}
+
+// 1: the device adds same-address lanes in lane order, 0: it does not (mask of failing patterns in *mask), < 0: the probe could not run
+inline int single_probe(hipStream_t stream, int *mask)
+{
+    static std::mutex mtx;
+    static std::vector<int> cache;                          // per device: -1 unknown, else the failing-pattern mask
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(mtx);
+    if ((int)cache.size() <= dev) cache.resize(dev + 1, -1);
+    if (cache[dev] < 0) {
+        int *d = nullptr, v = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&d), sizeof(int)) != hipSuccess) return -1;
+        bool ok = hipMemsetAsync(d, 0, sizeof(int), stream) == hipSuccess;
+        if (ok) { hipLaunchKernelGGL(k_single_probe, dim3(1), dim3(64), 0, stream, d); ok = hipGetLastError() == hipSuccess; }
+        ok = ok && hipMemcpyAsync(&v, d, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+        (void)hipFree(d);
+        if (!ok) return -1;
+        cache[dev] = v;
+    }
+    int v = cache[dev];
+    if (const char *e = getenv("GBP_SINGLE_PROBE_FAIL")) v = atoi(e);          // test switch: pretend the probe saw this mask
+    if (mask) *mask = v;
+    return v == 0 ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------ host --
 
 // (Rounds 2-3 added the messages to a second group of up to 758 cameras in an extra pass over the stored messages, k_cam_pass: 138.7 us
@@ -569,6 +641,8 @@ struct FusedPlan {
     int n_blocks = 0, n_big = 0;
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
+    int single_probe = -1;                           // -1: SINGLE not wanted, no probe; 1: the device's lane order was verified; 0: it failed, rounds variant instead
+    int single_probe_mask = 0;                       // failing patterns of k_single_probe
     size_t shmem = 0;
     FusedArgs args{};
     int *d_big = nullptr;
@@ -658,6 +732,15 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
         if (keep_mib >= 0.0) pl.args.pin = (int)(std::max(0.0, keep_mib * MiB - fixed) / per_tile / pl.n_blocks);
         // few cameras: many factors of a 60-factor tile share one (fr1desk: 63 cameras, up to eight) -- the SINGLE variant of the accumulation
         pl.single = getenv("GBP_ACC_SINGLE") ? atoi(getenv("GBP_ACC_SINGLE")) : (p.C <= (pl.args.pin != 0x7fffffff ? 200 : 350) ? 1 : 0);      // (1M factors: 66.1 against 75.1 us per step at 64 cameras, 68.0 / 72.4 at 128, 69.7 / 71.6 at 200, 72.7 / 73.4 at 300, equal at 400, 75.2 / 74.3 at 500; beyond the cache size -- the pinned variant -- 2M factors: 135.4 / 148.3 at 100 cameras, 151.0 / 143.7 at 300)
+        if (pl.single) {                                    // the order SINGLE relies on is verified on this device before it is used (single_probe)
+            pl.single_probe = single_probe(stream, &pl.single_probe_mask);
+            if (pl.single_probe < 0) return -1;
+            if (pl.single_probe == 0) {
+                pl.single = 0;
+                fprintf(stderr, "[gbp] this device does not apply same-address LDS atomics of one instruction in lane order (probe mask 0x%x): "
+                                "the fused sweep uses one accumulation round per rank instead\n", pl.single_probe_mask);
+            }
+        }
         if (const char *e = getenv("GBP_FUSED_NT")) pl.args.nt = atoi(e);      // experiments: bit 0 lin rows, bit 1 message rows of the cacheable tiles
         if (getenv("GBP_PLAN_DEBUG")) fprintf(stderr, "[gbp] fused plan: T %d blocks %d touched %.1f MiB keep %.1f MiB pin %d tiles per workgroup\n", p.T, pl.n_blocks, touched / MiB, keep_mib, pl.args.pin);
     }
@@ -727,7 +810,10 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
 }
 
 // the general sweep's factor kernel: the persistent loop in its STAGED form (no table: any number of cameras)
-inline int staged_launch(const Params &p0, int robustify, int local_relin, int n_cus, int reverse, hipStream_t stream, unsigned long long *clk, int full_rows)
+// attr_set: the caller's per-handle flag -- the dynamic-LDS attribute is a property of (kernel, device), and handles of one process may
+// sit on different devices (ranks as threads)
+inline int staged_launch(const Params &p0, int robustify, int local_relin, int n_cus, int reverse, hipStream_t stream, unsigned long long *clk, int full_rows,
+                         bool *attr_set)
 {
     Params p = p0;
     p.robustify = robustify; p.local_relin = local_relin;
@@ -735,13 +821,12 @@ inline int staged_launch(const Params &p0, int robustify, int local_relin, int n
     a.reverse = reverse; a.clk = clk; a.full_rows = full_rows; a.pin = 0x7fffffff;
     const int n_blocks = std::max(1, std::min(p.T, n_cus));
     const size_t shmem = sizeof(double) * ((size_t)WAT_WAVES * STAGED_WAVE_DOUBLES + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!*attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_wat<0, WAT_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_wat<1, WAT_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_wat<2, WAT_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
             return (int)hipErrorUnknown;
-        attr_set = true;
+        *attr_set = true;
     }
     const dim3 grid(n_blocks), block(WAT_WAVES * 64);
     switch (p.loss) {

@@ -827,6 +827,44 @@ GBP_DEV bool peer_wait_row(const PeerWait &wait, int n_parts, int C, int c, int 
     return ok;
 }
 
+// Self-test of the peer-store exchange, run by every rank after gbp_ba_peer_connect and before the first sweep (gbp_ba_peer_selftest): ONE
+// wave stores a tagged probe row -- 27 values that depend on (sender, entry, test number) -- into the probe area of EVERY rank's mailbox
+// exactly the way the sweep's rows travel (write-through data stores, s_waitcnt, tag store), then waits for the probe rows of all
+// ranks in its own mailbox and compares every entry.  out[0] |= 1: a rank's row did not arrive in time, |= 2: it arrived with wrong
+// contents; out[1] = the (lowest) rank concerned.  A pair of devices whose mapping, atomics or ordering do not work shows up here, with a
+// name, instead of as a time-out or a wrong belief in the middle of a run.
+GBP_HD double peer_probe_value(int src, int k, unsigned long long seq) { return (double)(((long long)(src + 1) << 20) + ((long long)k << 12) + (long long)(seq & 0xfffu)); }     // (an integer: exact however it is evaluated)
+__global__ __launch_bounds__(64) void k_peer_selftest(PeerOut peer, const double *mine, int rank, long long timeout_ticks, int *out)
+{
+    const int lane = threadIdx.x;
+    for (int r = 0; r < peer.n; ++r)
+        if (lane < 27) peer_store(peer.dst[r] + lane, peer_probe_value(rank, lane, peer.seq));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        for (int r = 0; r < peer.n; ++r)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer.dst[r] + 27), peer.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bool arrived = true;
+    if (lane < peer.n) {
+        const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(mine + (size_t)lane * PEER_ROW + 27);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer.seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > timeout_ticks) { arrived = false; break; }
+        }
+    }
+    const unsigned long long late = __ballot(!arrived);
+    unsigned long long wrong = 0ull;
+    for (int r = 0; r < peer.n; ++r) {
+        if ((late >> r) & 1ull) continue;
+        const bool bad = lane < 27 && peer_load(mine + (size_t)r * PEER_ROW + lane) != peer_probe_value(r, lane, peer.seq);
+        if (__ballot(bad)) wrong |= 1ull << r;
+    }
+    if (lane == 0 && (late | wrong)) {
+        out[0] = (late ? 1 : 0) | (wrong ? 2 : 0);
+        out[1] = __ffsll((long long)(late | wrong)) - 1;
+    }
+}
+
 // general path / update_all_beliefs: the partial sums already sit in `partial` (C*27): one wave per camera moves its row
 __global__ __launch_bounds__(BLOCK) void k_peer_push(const double *__restrict__ partial, int C, PeerOut peer)
 {

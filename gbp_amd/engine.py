@@ -25,11 +25,18 @@ def eval_fn(K4, x9, device=0):
     return h, J, hp
 
 
+def _sweep_flags(fused):
+    return 0 if fused is None else (_capi.FLAG_FORCE_FUSED if fused else _capi.FLAG_NO_FUSED)
+
+
 class BAEngine:
     def __init__(self, K, cam_means, lmk_means, meas, cam_idx, lmk_idx, *, gauss_noise_std=2.0, loss=None,
                  Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8, eta_damping=0.4,
-                 device=0, fused=True, device_pointers=None):
-        """device_pointers = (C, L, F): the five arrays are then integer DEVICE addresses on `device` (float64 cam_means[C,6],
+                 device=0, fused=None, device_pointers=None):
+        """fused: None = the library picks the sweep (the fused one, unless the graph has more cameras than its LDS table holds or so few
+        factors per camera and workgroup that the staged general sweep is faster); True = the fused sweep whatever the sparseness rule
+        says (GBP_FLAG_FORCE_FUSED); False = the general sweep (GBP_FLAG_NO_FUSED).
+        device_pointers = (C, L, F): the five arrays are then integer DEVICE addresses on `device` (float64 cam_means[C,6],
         lmk_means[L,3], meas[F,2]; int32 cam_idx[F], lmk_idx[F]) and nothing is uploaded (GBP_FLAG_DEVICE_INPUT)."""
         self._lib = _capi.load()
         if device_pointers is not None:
@@ -60,7 +67,7 @@ class BAEngine:
         d.gauss_noise_std = float(gauss_noise_std)
         d.loss = _capi.LOSS[loss]
         d.num_undamped_iters, d.min_linear_iters = int(num_undamped_iters), int(min_linear_iters)
-        d.flags = 0 if fused else _capi.FLAG_NO_FUSED
+        d.flags = _sweep_flags(fused)
         d.nstds, d.beta, d.eta_damping = float(Nstds), float(beta), float(eta_damping)
         self._h = ct.c_void_p()
         check(self._lib.gbp_ba_create(ct.byref(self._h), ct.byref(d)))
@@ -87,7 +94,7 @@ class BAEngine:
         d.gauss_noise_std = float(gauss_noise_std)
         d.loss = _capi.LOSS[loss]
         d.num_undamped_iters, d.min_linear_iters = int(num_undamped_iters), int(min_linear_iters)
-        d.flags = (0 if fused else _capi.FLAG_NO_FUSED) | _capi.FLAG_DEVICE_INPUT
+        d.flags = _sweep_flags(fused) | _capi.FLAG_DEVICE_INPUT
         d.nstds, d.beta, d.eta_damping = float(Nstds), float(beta), float(eta_damping)
         self._h = ct.c_void_p()
         check(self._lib.gbp_ba_create(ct.byref(self._h), ct.byref(d)))
@@ -220,6 +227,11 @@ class BAEngine:
             raise ValueError("every handle must be the 64 bytes of peer_export()")
         flags = (_capi.PEER_SAME_PROCESS if same_process else 0) | (_capi.PEER_RENDEZVOUS if rendezvous else 0)
         check(self._lib.gbp_ba_peer_connect(self._h, int(rank), len(handles), ct.c_char_p(blob), flags))
+
+    def peer_selftest(self, timeout_ms=5000):
+        """After peer_connect and a barrier of the side channel, on every rank: a tagged probe row to every rank's mailbox and the check
+        of everybody's on arrival (gbp_ba_peer_selftest).  Raises GbpError naming the pair that failed."""
+        check(self._lib.gbp_ba_peer_selftest(self._h, int(timeout_ms)))
 
     def comm_destroy(self):
         check(self._lib.gbp_ba_comm_destroy(self._h))
@@ -399,3 +411,10 @@ class BAEngine:
         a, b, c = ct.c_int32(), ct.c_int32(), ct.c_int32()
         check(self._lib.gbp_ba_info(self._h, ct.byref(a), ct.byref(b), ct.byref(c)))
         return dict(fused=bool(a.value), cam_groups=a.value, n_tiles=b.value, n_blocks=c.value)
+
+    def plan_info(self):
+        """What the sweep's plan decided (gbp_ba_plan_info): which sweep and why, the SINGLE accumulation variant and its probe."""
+        v = np.zeros(_capi.PLAN_INFO_FIELDS, np.int32)
+        check(self._lib.gbp_ba_plan_info(self._h, iptr(v), v.size))
+        return dict(fused=bool(v[0]), staged_by_sparseness=bool(v[1]), single=bool(v[2]), single_probe=int(v[3]), pinned_tiles=int(v[4]),
+                    n_blocks=int(v[5]), n_tiles=int(v[6]), n_big_landmarks=int(v[7]))

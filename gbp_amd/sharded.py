@@ -100,7 +100,21 @@ class _HipShard:
             oks = [None] * world
             dist.all_gather_object(oks, err)                 # also the barrier: nobody stores into a mailbox its owner has not set up yet
             bad += [o for o in oks if o is not None]
+            if not bad and not threads:
+                # Before the first sweep: one tagged probe row from every rank to every rank, checked on arrival (gbp_ba_peer_selftest).
+                # A pair of devices whose peer mapping does not work shows up HERE, by name, and the caller falls back to RCCL.
+                try:
+                    self.engine.peer_selftest(int(float(__import__('os').environ.get('GBP_PEER_SELFTEST_MS', '5000'))))
+                    err = None
+                except Exception as e:                       # noqa: BLE001
+                    err = f"error: {e}"
+                dist.all_gather_object(oks, err)
+                bad += [o for o in oks if o is not None]
             if bad:
+                try:
+                    self.engine.comm_destroy()               # (unmaps the peers' mailboxes: the handle is back to "no exchange")
+                except Exception:                            # noqa: BLE001
+                    pass
                 raise RuntimeError(f"peer-store exchange could not be set up ({bad[0]})")
         elif exchange == 'rccl':
             # rank 0 may fail to make the id (librccl not loadable): everybody must still leave the broadcast
@@ -140,7 +154,7 @@ class _HipShard:
 class ShardedBA:
     """BAFactorGraph surface (gbp_ba.py:12-69) over `world` ranks; every rank calls every method."""
 
-    def __init__(self, problem: BAProblem, device=0, fused=True, engine_factory=None, dist=None, library_loop=True,
+    def __init__(self, problem: BAProblem, device=0, fused=None, engine_factory=None, dist=None, library_loop=True,
                  always_exchange=False, exchange='auto', **cfg):
         if dist is None:
             import torch.distributed as dist
@@ -160,16 +174,30 @@ class ShardedBA:
         self._gathered = self.shard.new_buffer(n * self.world)
         self.library_loop = False
         self.exchange = 'python'                            # how the camera partial sums travel: python | rccl | peer | callback
+        self.exchange_fallback = None                       # why the exchange that was asked for is not the one in use (or None)
         if hasattr(self.shard, 'init_comm') and library_loop:
             # every rank must take the same path: agree on whether the library's communicator came up everywhere, else all
             # ranks drive the sweep from Python over the process group (slower per sweep, same results)
+            import sys
             try:
                 self.exchange = self.shard.init_comm(dist, always_exchange, exchange)
                 ok = 1
             except Exception as e:                          # noqa: BLE001 -- reported below, the job goes on
-                import sys
-                print(f"[gbp_amd] rank {self.rank}: in-library exchange unavailable ({e}); Python-driven loop instead", file=sys.stderr)
                 ok = 0
+                self.exchange_fallback = f"{exchange}: {e}"
+                # init_comm fails on ALL ranks together (its failures travel as data): every rank takes the same way out.  The peer-store
+                # exchange falls back to the library's RCCL all-gather when the process group can carry one (one rank per device).
+                rccl_possible = (exchange == 'peer' and not hasattr(dist, 'device_exchange')
+                                 and not (hasattr(dist, 'get_backend') and dist.get_backend() == 'gloo'))
+                if rccl_possible:
+                    print(f"[gbp_amd] rank {self.rank}: peer-store exchange unavailable ({e}); RCCL all-gather instead", file=sys.stderr)
+                    try:
+                        self.exchange = self.shard.init_comm(dist, always_exchange, 'rccl')
+                        ok = 1
+                    except Exception as e2:                 # noqa: BLE001
+                        self.exchange_fallback += f"; rccl: {e2}"
+                if not ok:
+                    print(f"[gbp_amd] rank {self.rank}: in-library exchange unavailable ({self.exchange_fallback}); Python-driven loop instead", file=sys.stderr)
             if hasattr(dist, 'device_exchange'):
                 self.library_loop = bool(ok)
             else:

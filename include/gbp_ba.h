@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GBP_ABI_VERSION 2      /* 2: gbp_ba_info's fused_path counts camera groups, state blobs are version 4, peer-store exchange, sweep clocks */
+#define GBP_ABI_VERSION 3      /* 3: gbp_ba_info's fused_path is 0 / 1, GBP_FLAG_FORCE_FUSED, gbp_ba_plan_info, gbp_ba_peer_selftest; gbp_ba_grouped_max_cams is gone.  State blobs are version 7. */
 
 enum {
     GBP_OK = 0,
@@ -66,6 +66,8 @@ typedef struct gbp_ba_desc {
 } gbp_ba_desc_t;
 
 #define GBP_FLAG_NO_FUSED 1       /* force the general 3-kernel sweep (testing / ablation) */
+#define GBP_FLAG_FORCE_FUSED 4    /* never leave the fused sweep on sparseness grounds (by default a graph with few factors per camera and
+                                     workgroup runs the staged general sweep, which is the faster one there; tests name the sweep they mean) */
 #define GBP_FLAG_DEVICE_INPUT 2   /* cam_means / lmk_means / meas / cam_idx / lmk_idx are DEVICE pointers (on desc.device): nothing is
                                      uploaded; the graph is ordered, tiled and linearised where the observations already are */
 
@@ -183,6 +185,10 @@ int gbp_ba_comm_destroy(gbp_ba_t *h);
 #define GBP_PEER_MAX_RANKS 16
 int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t flags);
 int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *handles, int32_t flags);
+/* after connect (and a side-channel barrier), before the first sharded call, on every rank: one tagged probe row travels to every
+ * rank's mailbox exactly as a sweep's rows do and the rows of all ranks are checked on arrival.  GBP_ESTATE names the pair that failed
+ * (row late, or wrong contents); the caller then uses the RCCL exchange (gbp_amd/sharded.py does, and records why). */
+int gbp_ba_peer_selftest(gbp_ba_t *h, int32_t timeout_ms);
 int gbp_ba_iterate_sharded(gbp_ba_t *h, int32_t n_iters, int32_t robustify, int32_t local_relin);   /* n x synchronous_iteration gbp.py:86-92 */
 int gbp_ba_update_beliefs_sharded(gbp_ba_t *h);                                                     /* update_all_beliefs gbp.py:56-58 */
 
@@ -227,9 +233,15 @@ enum { GBP_COMM_NONE = 0, GBP_COMM_CALLBACK = 1, GBP_COMM_RCCL = 2, GBP_COMM_PEE
 int gbp_ba_comm_info(gbp_ba_t *h, int32_t *kind, int32_t *rank, int32_t *n_ranks);
 int gbp_ba_get_kernel_times(gbp_ba_t *h, double *ms, int32_t cap, int32_t *n_launches);   /* each bracketed launch, in order; call BEFORE get_kernel_timing (which resets) */
 int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_blocks);   /* fused_path: 0 = general sweep (camera-major staging, any number of cameras), 1 = fused sweep (camera table in LDS) */
+/* what the plan of this handle's sweep decided, out[0..n): [0] fused sweep (1) or general sweep (0); [1] the general sweep was picked
+ * by the sparseness rule (few factors per camera and workgroup), not asked for; [2] the fused sweep adds all same-camera lanes of a
+ * tile in ONE LDS atomic instruction (the SINGLE variant: graphs of few cameras); [3] the probe of the lane order SINGLE relies on,
+ * run at create on the handle's device: 1 passed, 0 failed (the rounds variant runs instead), -1 SINGLE was not wanted; [4] tiles per
+ * workgroup that keep using the memory-side cache (-1: all of them); [5] workgroups; [6] tiles; [7] landmarks larger than a tile */
+#define GBP_PLAN_INFO_FIELDS 8
+int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n);
 int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols);   /* debug builds with -DGBP_PHASE_TIMING only (tools/phase_profile.py): per-wave time per phase of the last fused sweep */
 int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots);   /* debug: slots whose (camera, landmark) do not match the reference factor they hold (0 = sound) */
-int gbp_ba_grouped_max_cams(void);  /* = gbp_ba_fused_max_cams() since round 4 (the extra camera-group pass is gone); kept for ABI stability */
 int gbp_ba_fused_max_cams(void);    /* most cameras of the fused sweep (camera table + wave scratch in 160 KB of LDS); above it the general sweep runs */
 
 #ifdef __cplusplus

@@ -355,7 +355,47 @@ def g13(ref):
     save('G13_damped_relinearisation_vsmall', **out)
 
 
-ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13)
+G14_CHECKPOINTS = (30, 40, 50, 75, 100, 125, 150, 175, 200)
+
+
+def g14(ref, which=('vsmall', 'small', 'vsmall_huber')):
+    """ba.py at its DEFAULT length (ba.py:13 `--n_iters 200`, the loop ba.py:84-105) on fr1desk_vsmall and fr1desk_small with
+    ba.py's default flags, and on fr1desk_vsmall with `--loss huber`: ARE / energy / number of freshly relinearised factors before
+    every sweep, all beliefs (eta, Lambda, mean) after the sweeps of G14_CHECKPOINTS, and `iters_since_relin` of every factor at
+    those checkpoints (where two trajectories part, this is the first thing to differ).  One file per run: they take 90-200 s of
+    reference time each and can be made in parallel (`--only G14:small`)."""
+    from gbp import gbp_ba
+    runs = dict(vsmall=('fr1desk_vsmall.txt', {}), small=('fr1desk_small.txt', {}), vsmall_huber=('fr1desk_vsmall.txt', dict(loss='huber')))
+    for tag in which:
+        fname, over = runs[tag]
+        cfg = default_configs(**over)
+        graph = gbp_ba.create_ba_graph(os.path.join(HERE, 'data', fname), cfg)
+        graph.generate_priors_var(weaker_factor=cfg['prior_std_weaker_factor'])
+        graph.update_all_beliefs()
+        out, are, energy, relins = {}, [], [], []
+        for i in range(200):
+            if i == 3 or i == 8:
+                for f in graph.factors:
+                    f.iters_since_relin = 1
+            are.append(graph.are())
+            energy.append(graph.energy())
+            relins.append(sum(1 for f in graph.factors if f.iters_since_relin == 0))
+            graph.synchronous_iteration(robustify=True, local_relin=True)
+            k = i + 1
+            if k in G14_CHECKPOINTS:
+                for name, arr in beliefs_of(graph).items():
+                    out[f'it{k}_{name}'] = arr
+                out[f'it{k}_iters_since_relin'] = np.array([f.iters_since_relin for f in graph.factors], dtype=np.int32)
+        out['are_final'] = np.array(graph.are())
+        out['energy_final'] = np.array(graph.energy())
+        if over.get('loss'):
+            out['adaptive_var'] = np.array([f.adaptive_gauss_noise_var for f in graph.factors], dtype=np.float64)
+            out['robust_flag'] = np.array([f.robust_flag for f in graph.factors], dtype=np.uint8)
+        save(f'G14_200it_{tag}', bal=np.array(fname), loss=np.array(str(over.get('loss'))), checkpoints=np.array(G14_CHECKPOINTS),
+             are=np.array(are), energy=np.array(energy), n_relin=np.array(relins, dtype=np.int32), **out)
+
+
+ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
@@ -367,4 +407,8 @@ if __name__ == '__main__':
     warnings.simplefilter('ignore', SyntaxWarning)
     names = [s for s in args.only.split(',') if s] or list(ALL)
     for n in names:
-        ALL[n](args.reference)
+        n, _, sub = n.partition(':')
+        if sub:
+            ALL[n](args.reference, which=tuple(sub.split('+')))
+        else:
+            ALL[n](args.reference)

@@ -33,7 +33,7 @@ def test_header_symbols_all_exported_and_bound(capi):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported by libgbp_hip.so"
     assert set(names) == set(capi.SIGNATURES), set(names) ^ set(capi.SIGNATURES)
-    assert lib.gbp_abi_version() == capi.ABI_VERSION == 2
+    assert lib.gbp_abi_version() == capi.ABI_VERSION == 3
 
 
 def test_desc_struct_matches_header_layout(capi):

@@ -115,3 +115,33 @@ def test_factor_graph_surface_of_the_device_graph(compat_path):
     graph.synchronous_iteration(robustify=True, local_relin=True)
     assert graph.count_relinearising() == sum(1 for f in graph.factors if f.iters_since_relin == 0)
     assert np.array_equal(graph.factors[3].linpoint, graph._engine.factors(3, 1, dense=False)['linpoint'][0])
+
+
+def test_factor_views_held_across_device_calls(compat_path):
+    """The reference's Factor objects are long-lived: `f = graph.factors[0]` (or `fs = list(graph.factors)`) taken once and used across
+    synchronous_iteration() calls reads the CURRENT iters_since_relin, and a write through such a view reaches the sweep."""
+    from gbp import gbp_ba
+    configs = dict(gauss_noise_std=2, loss=None, Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8,
+                   eta_damping=0.4, prior_std_weaker_factor=50.0)
+    graph = gbp_ba.create_ba_graph(os.path.join(DATA, 'fr1desk_vsmall.txt'), configs)
+    graph.generate_priors_var(weaker_factor=50.0)
+    graph.update_all_beliefs()
+    f0 = graph.factors[0]
+    held = list(graph.factors)
+    assert f0.iters_since_relin == 0 and held[5].iters_since_relin == 0
+    graph.synchronous_iteration(robustify=True, local_relin=True)
+    assert f0.iters_since_relin == 1 and held[5].iters_since_relin == 1              # read through views taken BEFORE the sweep
+    assert np.array_equal(graph._engine.iters_since_relin(), [f.iters_since_relin for f in held])
+    graph.synchronous_iteration(robustify=True, local_relin=True)
+    held[7].iters_since_relin = 40                                                    # write through a stale-looking view ...
+    f0.iters_since_relin = 12
+    graph.synchronous_iteration(robustify=True, local_relin=True)
+    dev = graph._engine.iters_since_relin()
+    # ... is not lost: both factors were free to relinearise (>= min_linear_iters), so each is now at 0 (it did) or one past what was written
+    assert dev[7] in (0, 41) and dev[0] in (0, 13) and dev[3] == 3
+    assert held[7].iters_since_relin == dev[7] and f0.iters_since_relin == dev[0] and held[3].iters_since_relin == 3
+    # the ba.py pattern still works after all that: a loop writes everywhere, the next loop reads what the sweep made of it
+    for f in graph.factors:
+        f.iters_since_relin = 1
+    graph.synchronous_iteration(robustify=True, local_relin=True)
+    assert all(f.iters_since_relin == 2 for f in held)

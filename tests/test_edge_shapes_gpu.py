@@ -29,12 +29,14 @@ def test_camera_count_at_the_lds_boundary(oracle_mod):
     from gbp_amd import _capi
     cmax = _capi.load().gbp_ba_fused_max_cams()
     assert 256 <= cmax <= 758                       # 160 KB / 216 B per camera, minus the per-wave scratch
-    assert _capi.load().gbp_ba_grouped_max_cams() == cmax
-    # one table in LDS (fused sweep) / one camera more: the general sweep, the same loop with camera-major staging
+    # one table in LDS (fused sweep) / one camera more: the general sweep, the same loop with camera-major staging.  (5 400 factors on
+    # ~590 cameras are sparse: left to itself the library would run the staged sweep at every one of these sizes; fused=True asks for
+    # the fused sweep wherever its table fits, and above that it cannot be had.)
     for C, fused_path in ((cmax, 1), (cmax + 1, 0), (2 * cmax, 0)):
         prob = make_synthetic(n_cams=C, n_lmks=900, obs_per_lmk=6, seed=21)
-        gap, o, e = run_pair(oracle_mod, prob, n_sweeps=10)
+        gap, o, e = run_pair(oracle_mod, prob, n_sweeps=10, fused=True)
         assert e.info()['cam_groups'] == fused_path, (C, e.info())
+        assert e.plan_info()['staged_by_sparseness'] is False
         assert gap < BELIEF_TOL, (C, gap)
         for a, b in zip(e.messages(), o.messages()):
             assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
@@ -47,6 +49,9 @@ def test_sparse_graphs_take_the_staged_sweep(oracle_mod, monkeypatch):
     sparse = make_synthetic(n_cams=400, n_lmks=1500, obs_per_lmk=6, seed=4)          # 9 000 factors, 150 tiles x 400 cameras
     gap, o, e = run_pair(oracle_mod, sparse, n_sweeps=12)
     assert e.info()['cam_groups'] == 0 and gap < BELIEF_TOL, (e.info(), gap)
+    assert e.plan_info()['staged_by_sparseness'] is True
+    gap, o, e = run_pair(oracle_mod, sparse, n_sweeps=12, fused=True)                # ... unless the caller insists (GBP_FLAG_FORCE_FUSED)
+    assert e.info()['cam_groups'] == 1 and e.plan_info()['staged_by_sparseness'] is False and gap < BELIEF_TOL, (e.info(), gap)
     dense = make_synthetic(n_cams=12, n_lmks=1500, obs_per_lmk=6, seed=4)
     gap, o, e = run_pair(oracle_mod, dense, n_sweeps=12)
     assert e.info()['cam_groups'] == 1 and gap < BELIEF_TOL, (e.info(), gap)
@@ -106,6 +111,39 @@ def test_same_camera_lanes_in_one_atomic_instruction(monkeypatch):
             e.close()
         for mode in ('1', None):
             assert all(np.array_equal(a, b) for a, b in zip(out[mode], out['0'])), mode
+
+
+def test_single_variant_is_probed_on_the_device_and_falls_back(monkeypatch):
+    """The plan of a graph that selects the one-instruction accumulation first verifies, on the device it will run on, the lane order
+    that variant relies on (k_single_probe: seven address patterns, bitwise against lane-by-lane additions).  On this part the probe
+    passes; told that it failed (GBP_SINGLE_PROBE_FAIL = a failing-pattern mask: test switch) the plan runs the rounds variant --
+    same bits -- and gbp_ba_plan_info says so.  Graphs that never wanted the variant (many cameras) are not probed."""
+    import os
+    from conftest import DATA
+    from gbp_amd.balio import read_bal
+    from gbp_amd.engine import BAEngine
+    prob = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
+    out = {}
+    for fail in (None, '5'):
+        if fail is None:
+            monkeypatch.delenv('GBP_SINGLE_PROBE_FAIL', raising=False)
+        else:
+            monkeypatch.setenv('GBP_SINGLE_PROBE_FAIL', fail)
+        e = BAEngine.from_problem(prob, fused=True)
+        pi = e.plan_info()
+        assert pi['fused'] and pi['single'] == (fail is None) and pi['single_probe'] == (1 if fail is None else 0), pi
+        e.generate_priors_var(50.0)
+        e.update_all_beliefs()
+        e.set_iters_since_relin(8)
+        e.iterate(16)
+        out[fail] = [a.copy() for a in e.beliefs()]
+        e.close()
+    assert all(np.array_equal(a, b) for a, b in zip(out['5'], out[None]))
+    monkeypatch.delenv('GBP_SINGLE_PROBE_FAIL', raising=False)
+    e = BAEngine.from_problem(make_synthetic(n_cams=500, n_lmks=20_000, obs_per_lmk=10, seed=1), fused=True)
+    pi = e.plan_info()
+    assert pi['fused'] and not pi['single'] and pi['single_probe'] == -1 and pi['pinned_tiles'] == -1 and pi['n_blocks'] == 256, pi
+    e.close()
 
 
 def with_landmarks(p, degrees, seed=5):
@@ -330,3 +368,27 @@ def test_device_resident_checkpoint(fused):
     blob = e.save_state()                       # the host blob and the device slot are independent
     e.restore_snapshot(); e.iterate(2); e.load_state(blob)
     assert all(np.array_equal(x, y) for x, y in zip(a, e.beliefs()))
+
+
+def test_rejected_state_blob_leaves_the_handle_alone():
+    """gbp_ba_load_state validates version, sizes, graph hash and payload length BEFORE it touches the handle: a blob that
+    claims a dense message remainder but is too short for one used to switch the handle to the general sweep and then fail."""
+    from gbp_amd import _capi
+    from gbp_amd.engine import BAEngine
+    p = make_synthetic(n_cams=12, n_lmks=400, obs_per_lmk=5, seed=91)
+    e = BAEngine.from_problem(p, fused=True)
+    e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(3)
+    blob = e.save_state()
+    good = [a.copy() for a in e.beliefs()]
+    bad = blob.copy()
+    bad[20] |= 1                                  # StateHeader::reserved bit 0: "the payload ends with the dense remainder" -- it does not
+    with pytest.raises(_capi.GbpError, match='truncated'):
+        e.load_state(bad)
+    assert e.info()['fused'] and e.plan_info()['fused']
+    other = BAEngine.from_problem(make_synthetic(n_cams=12, n_lmks=400, obs_per_lmk=5, seed=92), fused=True)
+    with pytest.raises(_capi.GbpError, match='different graph'):
+        other.load_state(blob)
+    assert other.info()['fused']
+    e.iterate(2)
+    e.load_state(blob)                            # the untouched handle still takes the good blob and continues from it
+    assert all(np.array_equal(a, b) for a, b in zip(good, e.beliefs()))

@@ -331,3 +331,34 @@ def test_g13_damped_relinearisation_against_the_reference(oracle_mod):
         return o
 
     g13_sequence(graph, g, oracle_mod.replay_ba, lambda o, tag: g13_check(g, o, tag, 1e-7, 1e-6))
+
+
+@pytest.mark.parametrize('tag,loss', [('vsmall', None), ('small', None), ('vsmall_huber', 'huber')])
+def test_g14_ba_default_length(oracle_mod, tag, loss):
+    """The reference's own run length (ba.py:13: 200 sweeps; fixture G14): the oracle relinearises the same factors in the same sweep
+    as the reference all the way -- from sweep ~60 on some factors relinearise in every sweep -- and its beliefs stay within 1e-6
+    (observed 2e-8) at every checkpoint.  The GPU twin of this test is tests/test_long_run_gpu.py."""
+    g = golden(f'G14_200it_{tag}')
+    p = read_bal(os.path.join(DATA, str(g['bal'])))
+    o = oracle_mod.OracleBA.from_problem(p, loss=loss)
+    o.generate_priors_var(50.0)
+    o.update_all_beliefs()
+    checkpoints = [int(c) for c in g['checkpoints']]
+    relin, gaps, ages_off = [], {}, {}
+
+    def grab(i, graph):
+        it = graph.relin_state()['iters_since_relin']
+        relin.append(int((it == 0).sum()))
+        if i in checkpoints:
+            gaps[i] = belief_gap(graph.beliefs(), g, f'it{i}_')
+            ages_off[i] = int((it != g[f'it{i}_iters_since_relin']).sum())
+        if i == 200:
+            final.update(graph.relin_state())
+    final = {}
+    ares, energies = oracle_mod.replay_ba(o, 201, diagnostics=True, on_iter=grab)
+    assert np.array_equal(np.array(relin[:200]), g['n_relin'])
+    assert np.allclose(ares[:200], g['are'], rtol=1e-6) and np.allclose(energies[:200], g['energy'], rtol=1e-5)
+    assert sorted(gaps) == checkpoints and all(v == 0 for v in ages_off.values()), ages_off
+    assert max(gaps.values()) < 1e-6, gaps
+    if loss:
+        assert np.allclose(final['adaptive_var'], g['adaptive_var'], rtol=1e-8) and np.array_equal(final['robust_flag'], g['robust_flag'])
