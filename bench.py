@@ -169,7 +169,10 @@ def measured_traffic():
     return d.get('traffic_bytes_per_launch'), name
 
 
-def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_graph, side_dev='cuda'):
+PEER_NOTE = {}            # why the peer-store exchange was not measured (rank-local: whatever THIS rank saw)
+
+
+def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_graph, side_dev='cuda', per_rank_of=None):
     """N > 1: the same job once more with the peer-store exchange (gbp_ba_peer_connect: the reduce kernels store the camera partial
     sums straight into every rank's mailbox over xGMI, the finish kernels poll arrival words; no collective call).  Every step
     is agreed on by all ranks; any failure (IPC handles, a time-out in the two-sweep probe) just returns None.  Returns the
@@ -186,8 +189,11 @@ def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_grap
     try:
         g = ShardedBA(problem, device=local_rank, fused=False if args.no_fused else None, exchange='peer')
         ok = g.exchange == 'peer'
+        if not ok:
+            PEER_NOTE['reason'] = f"peer-store exchange not available, ShardedBA used {g.exchange!r} instead ({g.exchange_fallback})"
     except Exception as e:                                     # noqa: BLE001
         print(f"[bench] peer-store exchange unavailable: {e}", file=sys.stderr)
+        PEER_NOTE['reason'] = f"peer-store exchange unavailable: {e}"
         ok = False
     if not agreed(ok):
         if g is not None:
@@ -201,6 +207,7 @@ def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_grap
         ok = True
     except Exception as e:                                     # noqa: BLE001
         print(f"[bench] peer-store exchange probe failed: {e}", file=sys.stderr)
+        PEER_NOTE['reason'] = f"two-sweep probe of the peer-store exchange failed: {e}"
         ok = False
     if not agreed(ok):
         g.close()
@@ -214,8 +221,11 @@ def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_grap
         m['matches_rccl'] = match
     except Exception as e:                                     # noqa: BLE001
         print(f"[bench] peer-store exchange run failed: {e}", file=sys.stderr)
+        PEER_NOTE['reason'] = f"the timed run with the peer-store exchange failed: {e}"
         m = None
     ok = agreed(m is not None)
+    if ok and per_rank_of is not None:
+        m['per_rank'] = per_rank_of(m, g)                      # (collective: every rank has a measurement at this point)
     g.close()
     return m if ok else None
 
@@ -488,18 +498,31 @@ def main(shard_factory=None, script=None):
         x = x[np.isfinite(x)]
         return float(x.mean()) if x.size else None
 
-    def gather_per_rank(m):
-        """(collective) per-rank device times of the instrumented replay"""
+    def gather_per_rank(m, g=None):
+        """(collective) per-rank device times of the instrumented replay, and each rank's own roofline: the bytes ITS shard's layout must
+        move per launch of the sweep kernel / that rank's mean launch time (the N > 1 counterpart of `roofline`: judgeable per device)"""
+        g = graph if g is None else g
         pic = kernel_picture(m, F)
         if dist is None or dry or not pic['n']:
             return None
+        info = g.info()
+        fused = bool(info.get('fused'))
+        lay = layout_bytes(g.F, g.L, C, info.get('n_blocks', 0), fused)
         mine = [mean_ms(pic[k], pic['ok']) or 0.0 for k in ('sweep', 'reduce', 'finish')] + [mean_ms(pic['step'], pic['ok'][:-1]) or 0.0,
-                float(graph.F), float(graph.comm_info()['n_ranks'])]
+                float(g.F), float(g.comm_info()['n_ranks']), float(g.L), float(lay), 1.0 if fused else 0.0,
+                mean_ms(pic['sweep'], np.isfinite(pic['sweep'])) or 0.0]
         t = torch.tensor(mine, dtype=torch.float64, device=side_dev)
         allr = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allr, t)
-        return [dict(rank=r, sweep_ms=v[0], reduce_and_exchange_ms=v[1], finish_ms=v[2], step_ms_device=v[3], n_factors=int(v[4]),
-                     ranks_reported_by_exchange=int(v[5])) for r, v in enumerate(x.cpu().tolist() for x in allr)]
+        out = []
+        for r, v in enumerate(x.cpu().tolist() for x in allr):
+            k_ms = v[9]                                           # all timed launches of this rank's sweep kernel (like roofline.kernel_avg_ms)
+            gbs = v[7] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            out.append(dict(rank=r, sweep_ms=v[0], reduce_and_exchange_ms=v[1], finish_ms=v[2], step_ms_device=v[3], n_factors=int(v[4]),
+                            ranks_reported_by_exchange=int(v[5]), n_lmks=int(v[6]), sweep="fused" if v[8] > 0.5 else "general",
+                            roofline={"bound": "hbm", "kernel_avg_ms": k_ms, "bytes_per_launch": int(v[7]), "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}))
+        return out
 
     def hbm_bound_size():
         """The headline graph's working set (~240 MB) sits inside the MI355X's 256 MiB memory-side cache, and the counters behind
@@ -619,6 +642,8 @@ def main(shard_factory=None, script=None):
                                    + ("" if args.bal else "(gbp_amd.synthetic.make_synthetic seed 0), ") + "ba.py defaults, loss=None",
                        "n_cams": C, "n_lmks": L, "n_factors": F,
                        "parallelism": par, "exchange": exchange_used if (world > 1 or args.sharded) else None,
+                       "exchange_requested": args.exchange if (world > 1 or args.sharded) else None,
+                       "exchange_fallback": getattr(graph, 'exchange_fallback', None),
                        "sweep": "fused" if fused else "general",
                        "loop": ("python" if (args.python_loop or dry) else "in-library") if (world > 1 or args.sharded) else "gbp_ba_iterate"},
             "timing": {"protocol": "state restored before every batch; W warm-up + K timed sweeps between barrier+synchronize; median over batches",
@@ -653,6 +678,7 @@ def main(shard_factory=None, script=None):
     pc = None if dry else parity_check(graph, problem, dist, torch, side_dev, world, local_rank)
     per_rank = gather_per_rank(m)
     alt = None
+    peer_unavailable = None
     if world > 1 and not dry and args.exchange == 'auto' and exchange_used == 'rccl':
         # The same job with the peer-store exchange (no collective call: reduce kernels store into the ranks' mailboxes over xGMI).
         # The RCCL result is complete at this point: should the newer path hang beyond its own time-outs, a watchdog prints that
@@ -668,14 +694,18 @@ def main(shard_factory=None, script=None):
         watchdog = threading.Timer(float(os.environ.get('GBP_BENCH_PEER_WATCHDOG_S', '240')), on_timeout)
         watchdog.daemon = True
         watchdog.start()
-        alt = try_peer_exchange(args, problem, local_rank, dist, torch, measure, graph, side_dev)
+        alt = try_peer_exchange(args, problem, local_rank, dist, torch, measure, graph, side_dev, gather_per_rank)
         watchdog.cancel()
         if alt is not None and float(np.median(alt['times'])) < float(np.median(m['times'])) and alt.get('matches_rccl'):
             m, alt = alt, dict(m, exchange='rccl')
             exchange_used = 'peer'
-            per_rank = gather_per_rank(m)
+            per_rank = m.pop('per_rank', per_rank)
         elif alt is not None:
+            alt.pop('per_rank', None)
             alt = dict(alt, exchange='peer')
+        else:
+            peer_unavailable = PEER_NOTE.get('reason') or ("the peer-store exchange failed on another rank (its stderr has the reason); "
+                                                           "the RCCL result stands")
     if args.dump_sweeps and rank == 0:
         np.savez(args.dump_sweeps, clk_us=m['clk'], event_ms=m['ev_ms'], relin=m['relin'], batch_s=m['times'])
 
@@ -687,6 +717,8 @@ def main(shard_factory=None, script=None):
             print(f"[bench] HBM-bound size run failed: {e}", file=sys.stderr)
     if rank == 0:
         out = assemble(m, alt, exchange_used, per_rank, pc, hbm)
+        if peer_unavailable:
+            out["other_exchange"] = {"exchange": "peer", "error": peer_unavailable}
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()

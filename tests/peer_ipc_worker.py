@@ -20,6 +20,26 @@ def main():
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     p = make_synthetic(n_cams=int(sys.argv[6]), n_lmks=int(sys.argv[7]), obs_per_lmk=10, seed=2)
+    if os.environ.get('GBP_TEST_SELFTEST_ONLY'):             # test_peer_selftest_names_the_pair_that_failed: rank 1 never sends its probe row
+        from gbp_amd._capi import GbpError
+        from gbp_amd.engine import BAEngine
+        e = BAEngine.from_problem(p)
+        handles = [None] * world
+        dist.all_gather_object(handles, e.peer_export(world))
+        e.peer_connect(rank, handles)
+        dist.barrier()
+        if rank == 0:
+            try:
+                e.peer_selftest(300)
+                print('SELFTEST-PASSED')
+            except GbpError as ex:
+                print('SELFTEST-FAILED', ex)
+        else:
+            print('SELFTEST-SKIPPED')
+        dist.barrier()
+        e.close()
+        dist.destroy_process_group()
+        return
     g = ShardedBA(p, device=0, exchange='peer')
     assert g.library_loop and g.exchange == 'peer', (g.library_loop, g.exchange)
     g.generate_priors_var(50.0)

@@ -25,7 +25,7 @@ def free_port():
     return port
 
 
-def run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks, extra_env=None):
+def run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks, extra_env=None, expect_fail=False):
     port = free_port()
     # The ranks SHARE one GPU here: a rank that waits inside its exchange launch holds LDS on the CUs it sits on, and another rank's
     # fused sweep needs a whole CU's LDS per workgroup -- with the production grid (128 workgroups) two waiting ranks can leave the
@@ -43,6 +43,8 @@ def run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks, extra_env=None):
                 q.kill()
             raise
         outs.append(out.decode(errors='replace'))
+    if expect_fail:
+        return outs
     for pr, out in zip(procs, outs):
         assert pr.returncode == 0, out[-3000:]
     return [np.load(os.path.join(tmp_path, f'rank{r}.npz')) for r in range(world)]
@@ -84,27 +86,46 @@ def test_peer_exchange_split_launches_between_processes(tmp_path):
     assert np.array_equal(ranks[0]['ce'], ranks[1]['ce'])
 
 
-def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """bench.py's N > 1 path on hardware, as far as a one-GPU box allows: `--gpus 2` spawns its two ranks (torchrun on 127.0.0.1), both
-    on device 0 (GBP_BENCH_SHARE_GPU), side channel gloo, camera exchange = peer stores between the two processes.  The line must
-    carry both ranks' device times and the rank count the exchange reports.  (Its `value` is two ranks time-slicing one GPU: not a
-    measurement of anything.)"""
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_bench_n_ranks_on_one_gpu(tmp_path, world):
+    """bench.py's N > 1 path on hardware, as far as a one-GPU box allows: `--gpus N` spawns its N ranks (torchrun on 127.0.0.1), all
+    on device 0 (GBP_BENCH_SHARE_GPU), side channel gloo, camera exchange = peer stores between the processes (after the self-test of
+    gbp_ba_peer_selftest).  The line must carry every field a SCALE line is judged by: every rank's device times and its own roofline,
+    the rank count the exchange reports, the parity check against the reference's own run of this graph.  (Its `value` is N ranks
+    time-slicing one GPU: not a measurement of anything -- `one_rank_per_device` is false and says so.)"""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(GBP_BENCH_SHARE_GPU='1', GBP_XCHG_BLOCKS='16', HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_PEER_TIMEOUT_MS='8000')
-    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+    env.update(GBP_BENCH_SHARE_GPU='1', GBP_XCHG_BLOCKS='16', HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_PEER_TIMEOUT_MS='20000')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(world), '--steps', '20', '--warmup', '5',
            '--backend', 'gloo', '--exchange', 'peer', '--single-batch']          # the headline graph: parity_check has its fixture
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['exchange'] == 'peer' and out['config']['loop'] == 'in-library'
-    assert len(out['per_rank']) == 2 and all(pr['ranks_reported_by_exchange'] == 2 for pr in out['per_rank'])
-    assert sum(pr['n_factors'] for pr in out['per_rank']) == 1_000_000
+    if os.environ.get('GBP_KEEP_BENCH_LINES'):               # (tools/profile_round.sh keeps the lines as profiles/r05_bench_gpusN_shared_gpu_sample.json)
+        with open(os.path.join(os.environ['GBP_KEEP_BENCH_LINES'], f'bench_gpus{world}_shared_gpu.json'), 'w') as f:
+            json.dump(out, f, indent=1)
+    cfg = out['config']
+    assert out['n_gpus'] == world and out['value'] > 0 and out['scaling'] == 'strong'
+    assert cfg['exchange'] == 'peer' and cfg['exchange_requested'] == 'peer' and cfg['exchange_fallback'] is None and cfg['loop'] == 'in-library'
+    assert len(out['per_rank']) == world and all(pr['ranks_reported_by_exchange'] == world for pr in out['per_rank'])
+    assert sum(pr['n_factors'] for pr in out['per_rank']) == 1_000_000 and sum(pr['n_lmks'] for pr in out['per_rank']) == 100_000
+    for pr in out['per_rank']:                                # every rank's own roofline: its shard's layout bytes / its sweep kernel's time
+        rf = pr['roofline']
+        assert pr['sweep'] in ('fused', 'general') and rf['bound'] == 'hbm' and rf['bytes_per_launch'] > 0.9 * pr['n_factors'] * 256
+        assert 0.0 < rf['frac'] <= 1.0 and rf['kernel_avg_ms'] > 0 and abs(rf['achieved'] - rf['bytes_per_launch'] / rf['kernel_avg_ms'] / 1e6) < 1e-6 * rf['achieved']
+        assert pr['sweep_ms'] > 0 and pr['reduce_and_exchange_ms'] > 0 and pr['step_ms_device'] > 0
     # the line proves itself: ten sweeps outside the timed region against the REFERENCE's own run of this graph (fixture G9b)
     pc = out['parity_check']
-    assert pc['ok'] is True and pc['camera_beliefs_bitwise_equal_across_ranks'] is True and pc['ranks_reported_by_exchange'] == 2
+    assert pc['ok'] is True and pc['camera_beliefs_bitwise_equal_across_ranks'] is True and pc['ranks_reported_by_exchange'] == world
     assert pc['camera_belief_gap_vs_reference'] < 1e-6 and pc['are_trace_max_rel_err'] < 1e-6 and len(pc['are_trace']) == 11
-    assert pc['distinct_devices'] == 1 and pc['one_rank_per_device'] is False      # (two ranks share this box's one GPU, and the line says so)
-    assert all(pr['sweep_ms'] > 0 and pr['reduce_and_exchange_ms'] > 0 for pr in out['per_rank'])
+    assert pc['distinct_devices'] == 1 and pc['one_rank_per_device'] is False      # (the ranks share this box's one GPU, and the line says so)
+
+
+def test_peer_selftest_names_the_pair_that_failed(tmp_path):
+    """gbp_ba_peer_selftest: a rank whose peer never sends its probe row (here: rank 1 connects but skips its self-test) gets GBP_ESTATE
+    naming the rank that did not arrive, within the given time -- not a hang, and not a wrong belief later."""
+    outs = run_ranks(tmp_path, 2, 2, 40, 2000, extra_env={'GBP_TEST_SELFTEST_ONLY': '1'}, expect_fail=True)
+    assert 'SELFTEST-FAILED' in outs[0] and 'probe row of rank 1 did not reach rank 0 within 300 ms' in outs[0], outs[0][-1500:]
+    assert 'SELFTEST-SKIPPED' in outs[1]
