@@ -2,19 +2,32 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so ships
 to the GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
+
+    python -m gbp_amd.build [--out PATH] [-DNAME[=VALUE] ...] [--flag=-Rpass-analysis=...]
+
+`--out` / `-D` build a scratch copy of the library (tools/profile_round.sh: -DGBP_FUSED_DBG_SWITCHES, tools/phase_profile.py:
+-DGBP_PHASE_TIMING) and leave the product library alone.
 """
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgbp_hip.so')
-SOURCES = ['gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip']
-DEPS = ['gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip', 'gbp_build.hpp', 'gbp_kernels.hpp', 'gbp_fused.hpp', 'gbp_math.hpp', 'gbp_balio.hpp',
-        os.path.join('..', '..', 'include', 'gbp_ba.h'), os.path.join('..', '..', 'include', 'gbp_lin.h')]
+# one translation unit per part of the C ABI (gbp_handle.hpp says which), compiled side by side and linked into ONE library
+SOURCES = ['gbp_capi.hip', 'gbp_capi_sweep.hip', 'gbp_capi_shard.hip', 'gbp_capi_views.hip', 'gbp_capi_state.hip', 'gbp_lin_capi.hip',
+           'gbp_sort.hip']
+HEADERS = ['gbp_handle.hpp', 'gbp_build.hpp', 'gbp_kernels.hpp', 'gbp_sweep_kernels.hpp', 'gbp_view_kernels.hpp', 'gbp_fused.hpp',
+           'gbp_fused_plan.hpp', 'gbp_math.hpp', 'gbp_balio.hpp', os.path.join('experimental', 'gbp_instrument.hpp'),
+           os.path.join('..', '..', 'include', 'gbp_ba.h'), os.path.join('..', '..', 'include', 'gbp_lin.h')]
+DEPS = SOURCES + HEADERS
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
 
 
 def hipcc_path():
@@ -31,16 +44,43 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False):
-    """ONE command line: the library's sha256 ties committed counter passes to the binary they measured (bench.py), and even a
-    remarks flag changes it (-Rpass-analysis=kernel-resource-usage: tools/resource_usage.py compiles a scratch copy for that)."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-ffp-contract=fast', '-o', LIB] + SOURCES
-    subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+def build(force=False, out=None, defines=(), extra_flags=(), capture=False):
+    """The same command lines every time: the library's sha256 ties committed counter passes to the binary they measured (bench.py),
+    and even a remarks flag changes it (tools/resource_usage.py compiles a scratch copy for that: out=..., extra_flags=...).
+    Returns the library's path (capture=True: (path, the compiler's stderr))."""
+    lib = out or LIB
+    if not force and out is None and not needs_build():
+        return (lib, '') if capture else lib
+    hipcc = hipcc_path()
+    flags = FLAGS + [f'-D{d}' for d in defines] + list(extra_flags)
+    log = []
+    with tempfile.TemporaryDirectory(prefix='gbp_build_') as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + '.o')
+            r = subprocess.run([hipcc] + flags + ['-c', src, '-o', obj], cwd=CSRC, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+            log.append(r.stderr)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs, cwd=CSRC, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"linking {lib} failed:\n{r.stderr[-6000:]}")
+    return (lib, ''.join(log)) if capture else lib
 
 
 if __name__ == '__main__':
-    print(build(force=True))
+    out, defines, extra = None, [], []
+    args = sys.argv[1:]
+    while args:
+        a = args.pop(0)
+        if a == '--out':
+            out = os.path.abspath(args.pop(0))
+        elif a.startswith('-D'):
+            defines.append(a[2:])
+        elif a.startswith('--flag='):
+            extra.append(a[len('--flag='):])
+        else:
+            raise SystemExit(f"unknown argument {a!r}")
+    print(build(force=True, out=out, defines=defines, extra_flags=extra))

@@ -334,4 +334,34 @@ __global__ __launch_bounds__(BLOCK) void k_graph_hash(const int *__restrict__ re
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 
+// ---- priors: per-factor maximum of Lambda_f (gbp_ba.py:27-31), weaken_priors (gbp_ba.py:36-42) ----
+// np.max(factor.factor.lam) per factor at its current linearisation point (gbp_ba.py:31); 0 for empty slots
+__global__ __launch_bounds__(BLOCK) void k_factor_lambda_max(Params p, double *__restrict__ fmax_out)
+{
+    const int slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= p.T * WTILE) return;
+    int cam, lmk;
+    if (!slot_info(p, slot, cam, lmk)) { fmax_out[slot] = 0.0; return; }
+    double x0[9], Jc[2][6], Jl[2][3], h[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
+    linearise(x0, p.K, Jc, Jl, h);
+    const double av = slot_avar(p, slot);
+    fmax_out[slot] = factor_lambda_max(Jc, Jl, 1.0 / av);
+}
+
+
+// BAFactorGraph.weaken_priors (gbp_ba.py:36-42): prior eta and Lambda of every variable times `factor`
+__global__ __launch_bounds__(BLOCK) void k_weaken_priors(Params p, double factor)
+{
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t nc = (size_t)p.C * 27, nl = (size_t)p.L * 9;
+    if (i < nc) p.cprior[i] *= factor;
+    else if (i < nc + nl) {
+        const size_t j = i - nc;
+        p.lrec[(j / 9) * LREC + LR_PRIOR + (j % 9)] *= factor;
+    }
+}
+
+
 }  // namespace gbp

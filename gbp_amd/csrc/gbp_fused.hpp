@@ -54,56 +54,10 @@
 // plan stays disabled and the general sweep runs.
 #pragma once
 #include "gbp_kernels.hpp"
-#include <cstdint>
-#include <cstdlib>
+#include "gbp_fused_plan.hpp"
 #include <mutex>
-#include <vector>
 
 namespace gbp {
-
-constexpr int LDS_BYTES = 160 * 1024;
-constexpr int TROW = 28;                            // doubles per row of the workgroup tables in HBM (27 + pad: 16-byte stores / loads)
-#ifndef GBP_WAT_WAVES
-#define GBP_WAT_WAVES 8
-#endif
-constexpr int WAT_WAVES = GBP_WAT_WAVES;            // two waves per SIMD.  Round 4 built the three-waves-per-SIMD variant the covariance-form
-                                                    // factor core makes possible (-DGBP_WAT_WAVES=12: <= 168 VGPRs, twelve [64][9] message
-                                                    // scratches beside a 500-camera table) and measured it SLOWER on MI355X: 118 us per sweep
-                                                    // with the relinearisation path in the kernel (55 registers spilled), 99-102 us without it
-                                                    // (9 spilled, nothing in the loop) against 66.8 us for eight waves -- every phase that
-                                                    // only issues vector-memory instructions takes twice as long, and the slowest workgroup
-                                                    // finishes 33 % after the mean (profiles/r04_waves12_*.txt).  The CU's memory pipeline is
-                                                    // the limit; more waves queue in front of it.
-constexpr int WAVE_LDS_DOUBLES = WTILE * 9;        // per-wave scratch: [24][10] landmark heads (mean | covariance | rows), then [64][9] messages
-static_assert(TILE_LMKS * LHEAD <= WAVE_LDS_DOUBLES, "landmark heads of a tile must fit the wave scratch");
-
-// The GBP_FUSED_DBG ablation switches are compiled into the sweep only with -DGBP_FUSED_DBG_SWITCHES (tools/profile_round.sh builds that
-// copy of the library for its timing-only ablations): as run-time tests they put half a dozen scalar branches into every tile of the
-// product kernel.
-#ifdef GBP_FUSED_DBG_SWITCHES
-#define GBP_DBG(a, bit) ((a).dbg & (bit))
-#else
-#define GBP_DBG(a, bit) 0
-#endif
-
-struct FusedArgs {
-    double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes
-    int acc_doubles;            // cameras of the group * 27
-    int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
-    int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
-    int nt;                     // which factor streams bypass the memory-side cache (issue_streams)
-    int dbg;                    // experiment switches (GBP_FUSED_DBG): 1 no ticket wait, 2 no accumulation, 4 no landmark phase,
-                                // 8 camera records gathered from 8 cameras only (cheap for the address coalescer; wrong results),
-                                // 32 only the first round of the accumulation (same-camera duplicates of a tile dropped)
-    unsigned long long *phase;  // GBP_PHASE_TIMING builds only: [workgroup][wave][NPHASE] accumulated s_memtime ticks, or NULL
-    unsigned long long *clk;    // instrumented runs (gbp_ba_set_kernel_timing): where workgroup 0 stores the device's constant-rate clock
-                                // (wall_clock64) when it starts, or NULL.  HIP events around a launch also time the dispatch after the
-                                // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
-    int pin;                    // the first `pin` tiles of every workgroup's range use the memory-side cache as `nt` says; the rest stream
-                                // PAST it altogether, loads and message stores (fused_plan: graphs beyond the cache size)
-    int full_rows;              // STAGED: write whole camera-message rows (the staged x0 halves cannot be trusted: first staged sweep after
-                                // create / restore / a sweep of another kind); else only tiles in which a factor relinearised do
-};
 
 // Instrumented launches: workgroup 0 stores the clock when it starts (a grid starts first -> last within ~0.5 us).  One plain store:
 // an atomicMin / atomicMax from every workgroup on one word costs ~12 ns each at the memory side -- 500 of them made the reduce
@@ -113,23 +67,6 @@ GBP_DEV void clk_begin(unsigned long long *clk)
 {
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) *clk = (unsigned long long)wall_clock64();
 }
-
-// Phase profile of the persistent loop (tools/phase_profile.py builds the library with -DGBP_PHASE_TIMING): every wave adds
-// the s_memtime ticks it spends between consecutive marks into its own row.  Off in the product build (no code at all).
-constexpr int NPHASE = 12;
-#ifdef GBP_PHASE_TIMING
-#define GBP_PH_DECL unsigned long long ph_last = __builtin_amdgcn_s_memtime(), ph_acc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define GBP_PH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
-                       ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
-#define GBP_PH_NOWAIT(i) do { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
-#define GBP_PH_FLUSH(ptr, row) do { if ((ptr) && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < NPHASE; ++i_) (ptr)[(size_t)(row) * NPHASE + i_] = ph_acc[i_]; } while (0)
-#else
-#define GBP_PH_DECL
-#define GBP_PH(i)
-#define GBP_PH_NOWAIT(i)
-#define GBP_PH_FLUSH(ptr, row)
-#endif
-
 
 // Accesses of the persistent loop: a wave-uniform base pointer (SGPR pair) + an unsigned 32-bit lane offset, so that the address of
 // a load or store costs ONE vector register (global_load ... v_off, s[base:base+1]) instead of a 64-bit pair per access -- with
@@ -301,9 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
         // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
-#if !(defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 2)
         if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
-#endif
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(2);                                  // landmark beliefs of the previous tile (LDS)
 
@@ -354,19 +289,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             tile_relin = relin_in_wave(relin);
             n_relin += tile_relin;
             GBP_PH_NOWAIT(6);                              // the maths
-#if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1        // (this half's share of the stores: q_L, V_L)
-            st2(msg_w, 1024u + lo, qL[0], qL[1]);
-            wave_lds_sync();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eL[k];
-            st1(msg_w, 3072u + lo + 8u, VL[0]); st2(msg_w, 4096u + lo, VL[1], VL[2]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-#elif defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 2      // (q_C, W_C)
-            st2(msg_w, lo, qC[0], qC[1]);
-            wave_lds_sync();
-            st2(msg_w, 2048u + lo, WC[0], WC[1]); st1(msg_w, 3072u + lo, WC[2]);
-#else
             // (one wave-uniform branch around the whole block: five branches, one per store, cost the pinned variant 2-3 us per sweep)
 #define GBP_MSG_STORES(ST)                                                                                            \
             ST(msg_w, lo, qC[0], qC[1]); ST(msg_w, 1024u + lo, qL[0], qL[1]);                                         \
@@ -376,7 +298,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
             _Pragma("unroll") for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
             if (past) { GBP_MSG_STORES(st2_nt) } else { GBP_MSG_STORES(st2) }
 #undef GBP_MSG_STORES
-#endif
             if (st != (int)(words >> 32))                   // the state word (high half of ROW_SM): only a factor that did more than age has a new one
                 *reinterpret_cast<int *>(reinterpret_cast<char *>(lin_w) + 5120u + lo + 12u) = st;
             if (LOSS != 0) *reinterpret_cast<double *>(reinterpret_cast<char *>(p.avar + (size_t)t * WTILE) + (unsigned)lane * 8u) = avar;
@@ -417,9 +338,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         const int rank = state_rank(st);
         const int cloc = cam - a.cam_base;
         const bool mine = active && (unsigned)cloc < (unsigned)a.cam_count;
-#if defined(GBP_EXPERIMENT_HALF) && GBP_EXPERIMENT_HALF == 1
-        for (int r = 0; r < 0; ++r) {
-#else
         // Lanes of a tile that hit the same camera add in rank (= lane) order.  Few of them: one round per rank, one lane per camera in
         // every ds_add_f64.  Many (graphs with a few dozen cameras: fr1desk has 63, and up to eight factors of a tile on one of them):
         // ALL lanes in one instruction -- the LDS atomic unit applies the lanes that share an address in ascending lane order, which IS
@@ -428,7 +346,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // two duplicates per tile the rounds are faster (1M factors x 500 cameras: 74.3 against 75.2 us per step).
         // The choice is per graph (a kernel variant, fused_plan: by the number of cameras): a per-tile test cost the headline 0.8 us per sweep.
         for (int r = 0; r <= ((GBP_DBG(a, 32) || SINGLE) ? 0 : maxrank); ++r) {      // (dbg 32: first round only -- drops the duplicates, timing experiment)
-#endif
             if (mine && (SINGLE || rank == r) && !GBP_DBG(a, 2)) {
                 double *dst = acc + cloc * 27;
 #pragma unroll
@@ -635,59 +552,6 @@ inline int single_probe(hipStream_t stream, int *mask)
 // (Rounds 2-3 added the messages to a second group of up to 758 cameras in an extra pass over the stored messages, k_cam_pass: 138.7 us
 //  per sweep at C = 1000.  The general sweep's persistent STAGED form does the same graph in 127 us and has no camera limit: removed.)
 
-struct FusedPlan {
-    bool enabled = false;
-    int n_groups = 0, group_cams = 0;                // (one camera group: the whole table in LDS)
-    int n_blocks = 0, n_big = 0;
-    int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
-    int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
-    int single_probe = -1;                           // -1: SINGLE not wanted, no probe; 1: the device's lane order was verified; 0: it failed, rounds variant instead
-    int single_probe_mask = 0;                       // failing patterns of k_single_probe
-    size_t shmem = 0;
-    FusedArgs args{};
-    int *d_big = nullptr;
-    std::vector<void *> allocs;
-    void *(*alloc)(void *ctx, size_t bytes) = nullptr;   // optional: take device memory from the owner's arena (else hipMalloc)
-    void *alloc_ctx = nullptr;
-};
-
-inline void fused_destroy(FusedPlan &pl)
-{
-    for (void *q : pl.allocs) (void)hipFree(q);
-    pl.allocs.clear();
-    pl.enabled = false;
-}
-
-template <typename T>
-inline int fused_upload(FusedPlan &pl, T **dst, const T *src, size_t n, hipStream_t stream)
-{
-    void *q = pl.alloc ? pl.alloc(pl.alloc_ctx, std::max<size_t>(n, 1) * sizeof(T)) : nullptr;
-    if (!q) {
-        if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return -1;
-        pl.allocs.push_back(q);
-    }
-    if (src && n) {
-        if (hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
-        if (hipStreamSynchronize(stream) != hipSuccess) return -1;
-    }
-    *dst = static_cast<T *>(q);
-    return 0;
-}
-
-inline size_t fused_shmem(int C)
-{
-    const int acc_doubles = C * 27;
-    return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * WAVE_LDS_DOUBLES + 1);
-}
-
-// most cameras whose table + the per-wave scratch fit the LDS (the plan falls back to the general sweep above it)
-inline int fused_max_cams()
-{
-    int c = 0;
-    while (fused_shmem(c + 1) <= (size_t)LDS_BYTES) ++c;
-    return c;
-}
-
 // Workgroup tile ranges + per-workgroup camera tables; `big` = landmarks larger than a tile.
 inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
 {
@@ -705,12 +569,11 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * TROW, stream)) return -1;
     pl.n_big = (int)big.size();
     if (pl.n_big && fused_upload(pl, &pl.d_big, big.data(), big.size(), stream)) return -1;
-    const char *env_dbg = getenv("GBP_FUSED_DBG");
-    unsigned long long *d_phase = nullptr;
-#ifdef GBP_PHASE_TIMING
-    if (fused_upload<unsigned long long>(pl, &d_phase, nullptr, (size_t)pl.n_blocks * WAT_WAVES * NPHASE, stream)) return -1;
+    pl.args = FusedArgs{};
+    pl.args.block_partials = d_bp; pl.args.acc_doubles = acc_doubles; pl.args.cam_base = 0; pl.args.cam_count = std::min(p.C, pl.group_cams);
+#if defined(GBP_FUSED_DBG_SWITCHES) || defined(GBP_PHASE_TIMING)
+    if (instrument_plan(pl, stream)) return -1;             // experimental/gbp_instrument.hpp: GBP_FUSED_DBG, the phase buffer
 #endif
-    pl.args = FusedArgs{d_bp, acc_doubles, 0, std::min(p.C, pl.group_cams), 0, 0, env_dbg ? atoi(env_dbg) : 0, d_phase, nullptr};
     {
         // What a sweep touches, against the 256 MiB memory-side cache.  Everything fits: nothing bypasses it.  Beyond it the first
         // tiles of every workgroup's range -- 160 MiB worth, tables and records included -- keep using the cache and stay resident

@@ -32,6 +32,8 @@
 //            cbelief[C][28] = eta 6 | Lambda 21 | pad (views), cprior[C][27] = eta 6 | Lambda 21;  cptr[C+1], cadj[F] = slots of
 //            each camera's factors (reference order).
 //
+// (This header holds the layout and every device-side helper; the kernels themselves live with the translation unit that launches them:
+// gbp_sweep_kernels.hpp + gbp_fused.hpp -> gbp_capi_sweep.hip, gbp_view_kernels.hpp -> gbp_capi_views.hip, gbp_build.hpp -> gbp_capi.hip.)
 // General sweep (any shape) = k_factor_tile (one wave per tile: messages, the tile's landmark beliefs, camera messages
 // staged in camera-major order) -> k_lmk_belief_list (landmarks larger than a tile) -> k_cam_partial_staged (one
 // workgroup per camera, contiguous run) -> k_cam_finish.  k_lmk_belief / k_cam_partial form beliefs from the STORED
@@ -220,11 +222,7 @@ GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], 
                         double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr)
 {
     double d;
-#ifdef GBP_EXPERIMENT_NO_RELIN_PATH                          // timing experiment only (wrong results in relinearising sweeps)
-    const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d) && false;
-#else
     const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
-#endif
     Lin L;
     factor_linearise(p, x0, z, avar, d, L);
     double PL[6];
@@ -243,12 +241,8 @@ GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], 
             for (int i = 0; i < 3; ++i) x0[6 + i] = muL[i];
             store_x0(x0);                                  // at once: the stores' operands do not travel through the eliminations
         }
-#if !(defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 1))
         downdate<3>(PL, muL, L.Jl[0], L.Jl[1], VL, qL);
-#endif
-#if !(defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 2))
         downdate<6>(PC, muC, L.Jc[0], L.Jc[1], WC, qC);
-#endif
         if (XTRA) {
             // e_old = J_old^T q_old + x_old: the remainder leaves the cavity too (mu' -= P' x_old).  Damped in the very sweep it
             // relinearises: d e_old leaves the span of the new Jacobian and is carried densely; otherwise only the old remainder decays.
@@ -283,35 +277,14 @@ GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], 
         qC[0] = 0.0; qC[1] = 0.0; qL[0] = 0.0; qL[1] = 0.0;
     }
     double Vn[3], Wn[3], rL[2], rC[2];
-    // GBP_EXPERIMENT_HALF (timing and register-budget experiment only, wrong results): 1 = only the camera-eliminating half of a factor
-    // (message to the landmark), 2 = only the landmark-eliminating half (message to the camera) -- what each wave of a two-waves-per-tile
-    // split would run; 3 = neither (the loop's skeleton: streams, gathers, staging, stores, ordered section) (profiles/r04_factor_halves.json).
-#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 1)
-    Wn[0] = WC[0]; Wn[1] = WC[1]; Wn[2] = WC[2]; rC[0] = qC[0]; rC[1] = qC[1];
-#else
     eliminate<3>(PL, muL, L.Jl[0], L.Jl[1], VL, qL, L.rho, L.s, Wn, rC);      // landmark out: the message to the camera
-#endif
-#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 2)
-    Vn[0] = VL[0]; Vn[1] = VL[1]; Vn[2] = VL[2]; rL[0] = qL[0]; rL[1] = qL[1];
-#else
     eliminate<6>(PC, muC, L.Jc[0], L.Jc[1], WC, qC, L.rho, L.s, Vn, rL);      // camera out: the message to the landmark
-#endif
     qL[0] = (1.0 - d) * rL[0] + dqL[0]; qL[1] = (1.0 - d) * rL[1] + dqL[1];
     qC[0] = (1.0 - d) * rC[0] + dqC[0]; qC[1] = (1.0 - d) * rC[1] + dqC[1];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { VL[k] = Vn[k]; WC[k] = Wn[k]; }
-#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 2)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { MLn[k] = 0.0; if (k < 3) eLn[k] = 0.0; }
-#else
     dense_message<3>(L.Jl[0], L.Jl[1], qL, VL, eLn, MLn);
-#endif
-#if defined(GBP_EXPERIMENT_HALF) && (GBP_EXPERIMENT_HALF & 1)
-#pragma unroll
-    for (int k = 0; k < 21; ++k) { MCn[k] = 0.0; if (k < 6) eCn[k] = 0.0; }
-#else
     dense_message<6>(L.Jc[0], L.Jc[1], qC, WC, eCn, MCn);
-#endif
     if (XTRA) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { eCn[i] += xn[i]; xt[i] = xn[i]; }
@@ -484,189 +457,6 @@ GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int l0
     }
 }
 
-// ------------------------------------------------------------- general sweep, tile version --
-// One WAVE per tile: the per-factor part of synchronous_iteration (both messages computed from the OLD messages and
-// committed together, Factor.compute_messages gbp.py:334-373), plus what the tile structure gives for free when the
-// camera table of the fused sweep does not fit the LDS (C > 516):
-//   * the landmarks a tile owns get their beliefs from the same wave (new messages through LDS, prior + sum in
-//     adj_factors order, 3x3 solve) -- no second pass over the messages (k_lmk_belief re-reads and re-linearises them);
-//   * what rebuilds the message to the camera (x0 9 | q_C 2 | W 3: eta = Jc^T q_C, Lambda = Jc^T W Jc with Jc at x0 -- 14
-//     doubles instead of the dense 27) is written to cstage[cpos[slot]], i.e. in the camera's own
-//     adj_factors order, so k_cam_partial_staged reads one contiguous run per camera instead of gathering 16-byte
-//     pieces and rebuilding Jacobians (k_cam_partial fetches 562 MB per sweep at 1M factors; this is 216 + 216 MB).
-template <int LOSS, bool XTRA>
-__global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
-{
-    __shared__ __attribute__((aligned(16))) double wls[BLOCK / 64][WTILE * CSTAGE_ROW];  // per wave: [64][9] landmark messages, then [64][20] camera-message rows
-    __shared__ int wps[BLOCK / 64][WTILE];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int t = blockIdx.x * (BLOCK / 64) + wave;
-    if (t >= p.T) return;                                   // whole wave
-    if (p.reverse_walk) t = p.T - 1 - t;
-    double *wl = wls[wave];
-    int *wp = wps[wave];
-    const int4 td = p.tiles[t];
-    const int l0 = td.x, nl = td.y, nf = td.z;
-    const bool active = lane < nf;
-    const int slot = t * WTILE + lane;
-    double srow[XTRA ? CSTAGE_ROW : CSTAGE_PLAIN];          // x0 | q_C | W (| remainder, or two pad doubles) of this lane's factor AFTER the sweep
-    if (active) {
-        const unsigned meta = slot_meta(p, slot);
-        const int cam = (int)(meta >> META_LMK_BITS), lmk = l0 + (int)(meta & ((1u << META_LMK_BITS) - 1u));
-        double x0[9], z[2], qC[2], qL[2], WC[3], VL[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-        z[0] = p.lin[lin_at(slot, ROW_Z)]; z[1] = p.lin[lin_at(slot, ROW_Z + 1)];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { qC[k] = p.msg[msg_at(slot, ROW_QC + k)]; qL[k] = p.msg[msg_at(slot, ROW_QL + k)]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) WC[k] = p.msg[msg_at(slot, ROW_WC + k)];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) VL[k] = p.msg[msg_at(slot, ROW_VL + k)];
-        int st = slot_state(p, slot);
-        const int st_in = st;
-        double avar = (LOSS != 0) ? p.avar[slot] : p.sigma2;
-        double muC[6], PC[21], muL[3];
-        load_cam_record(p.cbel + (size_t)cam * CAMREC, muC, PC);
-        const double *lr = p.lrec + (size_t)lmk * LREC;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) muL[k] = lr[LR_MU + k];
-
-        double eCn[6], eLn[3], MCn[21], MLn[6];
-        const bool relin = factor_core<LOSS, XTRA>(p, x0, z, st, avar, muC, PC, muL,
-                                                   [lr](double (&c)[6]) {
-#pragma unroll
-                                                       for (int k = 0; k < 6; ++k) c[k] = lr[LR_COV + k];
-                                                   },
-                                                   [&p, slot](const double (&x)[9]) {
-#pragma unroll
-                                                       for (int k = 0; k < 9; ++k) p.lin[lin_at(slot, ROW_X0 + k)] = x[k];
-                                                   },
-                                                   qC, qL, WC, VL, eCn, eLn, MCn, MLn,
-                                                   XTRA ? p.xtra + (size_t)slot * XTRA_ROW : nullptr);
-        {
-            const unsigned long long rb = __ballot(relin);
-            if (rb != 0ull && lane == __ffsll((long long)rb) - 1) relin_add(p, __popcll(rb));
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { p.msg[msg_at(slot, ROW_QC + k)] = qC[k]; p.msg[msg_at(slot, ROW_QL + k)] = qL[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_WC + k)] = WC[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p.msg[msg_at(slot, ROW_VL + k)] = VL[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wl[lane * 9 + k] = eLn[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) wl[lane * 9 + 3 + k] = MLn[k];
-        if (st != st_in) set_slot_state(p, slot, st);
-        if (LOSS != 0) p.avar[slot] = avar;
-        wp[lane] = p.cpos[slot];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) srow[k] = x0[k];
-        srow[9] = qC[0]; srow[10] = qC[1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) srow[11 + k] = WC[k];
-        if (XTRA) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) srow[CSTAGE_USED + k] = p.xtra[(size_t)slot * XTRA_ROW + k];
-        }
-    }
-    if (p.stage & STAGE_NO_BELIEFS) return;                 // compute_all_messages on its own (gbp.py:46-54): whole wave
-    // VariableNode.update_belief gbp.py:176-198 for the tile's landmarks: nine lanes per landmark
-    LmkPre pre;
-    lmk_prefetch(p, lane, t, l0, nl, pre);
-    wave_lds_sync();                                        // the wave's LDS writes are done (one wave: no barrier needed)
-    tile_landmark_beliefs(p, wl, lane, l0, nl, pre);
-    // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
-    // transposed, whole rows go out, 16 bytes per lane
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
-    constexpr int R = XTRA ? CSTAGE_ROW : CSTAGE_PLAIN;
-    if (!XTRA) { srow[CSTAGE_USED] = 0.0; srow[CSTAGE_USED + 1] = 0.0; }
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < R; ++k) wl[lane * R + k] = srow[k];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-        constexpr int R2 = R / 2, PER2 = 64 / R2;           // 16 bytes per lane: eight whole 128-byte lines per instruction (six 160-byte rows with xtra)
-        const int g = lane / R2, k = 2 * (lane - g * R2);
-        if (g < PER2) {
-            for (int f = g; f < nf; f += PER2)
-                *reinterpret_cast<double2 *>(p.cstage + (size_t)wp[f] * R + k) = *reinterpret_cast<const double2 *>(wl + f * R + k);
-        }
-    }
-}
-
-// One workgroup per camera: partial[c][27] = sum of the messages of its factors, rebuilt from the staged rows (contiguous per
-// camera, in the reference's adj_factors order): every thread linearises its factors (every 256th of the run), adds their
-// eta = Jc^T q_C (+ remainder) and Lambda = Jc^T W Jc into 27 registers, then the block adds the threads up in a fixed order
-// (shuffle tree, then the four waves) -- bitwise reproducible.
-// finish != 0 (single GPU: nothing to exchange): the camera belief is completed here -- prior + sum, 6x6 solve (gbp.py:182-193) --
-// instead of in a dependent k_cam_finish launch.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__restrict__ partial, int finish)
-{
-    __shared__ double red[NT / 64][27];
-    __shared__ double tot[27];
-    const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    double acc[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    const int e1 = p.cptr[c + 1];
-    for (int e = p.cptr[c] + threadIdx.x; e < e1; e += NT) {
-        const double2 *row = reinterpret_cast<const double2 *>(p.cstage + (size_t)e * p.crow);
-        double v[CSTAGE_ROW];
-#pragma unroll
-        for (int i = 0; i < CSTAGE_USED / 2; ++i) { const double2 t = row[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
-        double x0[9], Jc[2][6], Jl[2][3], h[2], MC[21];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x0[k] = v[k];
-        linearise(x0, p.K, Jc, Jl, h);
-        const double W[3] = {v[11], v[12], v[13]};
-#pragma unroll
-        for (int k = 0; k < 21; ++k) MC[k] = 0.0;
-        rank2_update<6>(MC, Jc[0], Jc[1], W, 1.0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += Jc[0][k] * v[9] + Jc[1][k] * v[10];
-        if (p.xtra) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const double2 t = row[CSTAGE_USED / 2 + i]; acc[2 * i] += t.x; acc[2 * i + 1] += t.y; }
-        }
-#pragma unroll
-        for (int k = 0; k < 21; ++k) acc[6 + k] += MC[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        acc[k] = v;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) red[wave][k] = acc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 27) {
-        double s2 = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < NT / 64; ++w) s2 += red[w][threadIdx.x];
-        partial[(size_t)c * 27 + threadIdx.x] = s2;
-        tot[threadIdx.x] = s2 + p.cprior[(size_t)c * 27 + threadIdx.x];
-    }
-    if (!finish) return;
-    __syncthreads();
-    double *rec = p.cbel + (size_t)c * CAMREC;
-    if (threadIdx.x >= NT - 27) p.cbelief[(size_t)c * CBEL + threadIdx.x - (NT - 27)] = tot[threadIdx.x - (NT - 27)];
-    if (threadIdx.x < 7) {
-        double v[27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) v[k] = tot[k];
-        cam_belief_store(v, rec, threadIdx.x);
-    }
-}
-
 // ------------------------------------------------------------------ general sweep, stage 2 --
 // VariableNode.update_belief for one landmark (gbp.py:176-198): prior + messages in adj_factors order
 // (= ascending reference factor id = slot order inside the landmark), then mu = Lambda^-1 eta.
@@ -691,81 +481,6 @@ GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
     double acc[9];
     landmark_sum_from_hbm(p, l, acc);
     lmk_belief_store(acc, p.lrec + (size_t)l * LREC);
-}
-
-// VariableNode.belief (eta | Lambda) of every landmark as a view.  The sweep keeps a landmark belief in the form the factors read,
-// mean | covariance; its information form is Lambda = Sigma^-1, eta = Lambda mu -- the belief as of the last update_belief, whatever has
-// happened to messages or priors since (the stage-wise calls of gbp.py:46-84 change those without touching the beliefs).  The 3x3
-// round trip costs ~cond(Lambda) * 1e-16 relative (1e-10 on the shipped data) against 72 bytes per landmark and sweep that no kernel reads.
-__global__ __launch_bounds__(BLOCK) void k_lmk_belief_view(Params p, double *__restrict__ out)
-{
-    const int l = blockIdx.x * BLOCK + threadIdx.x;
-    if (l >= p.L) return;
-    const double *lr = p.lrec + (size_t)l * LREC;
-    double sig[6], lam[6], mu[3];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sig[k] = lr[LR_COV + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mu[k] = lr[LR_MU + k];
-    spd_inverse<3>(sig, lam);
-    out[(size_t)l * 9 + 0] = lam[0] * mu[0] + lam[1] * mu[1] + lam[2] * mu[2];
-    out[(size_t)l * 9 + 1] = lam[1] * mu[0] + lam[3] * mu[1] + lam[4] * mu[2];
-    out[(size_t)l * 9 + 2] = lam[2] * mu[0] + lam[4] * mu[1] + lam[5] * mu[2];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) out[(size_t)l * 9 + 3 + k] = lam[k];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
-{
-    const int l = blockIdx.x * BLOCK + threadIdx.x;
-    if (l < p.L) landmark_belief_from_hbm(p, l);
-}
-
-// beliefs of a list of landmarks (the ones larger than a tile, after the fused sweep)
-__global__ __launch_bounds__(64) void k_lmk_belief_list(Params p, const int *__restrict__ list, int n)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i < n) landmark_belief_from_hbm(p, list[i]);
-}
-
-// One workgroup per camera: sum of the messages of its factors (gathered through cadj), WITHOUT the
-// prior, into partial[c][27].  Fixed-shape reduction -> bitwise reproducible.
-__global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restrict__ partial)
-{
-    __shared__ double red[BLOCK / 64][27];
-    const int c = blockIdx.x;
-    double acc[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    const int e1 = p.cptr[c + 1];
-    for (int e = p.cptr[c] + threadIdx.x; e < e1; e += BLOCK) {
-        const int s = p.cadj[e];
-        double eC[6], MC[21], eL[3], ML[6];
-        dense_messages(p, s, eC, MC, eL, ML);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += eC[k];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) acc[6 + k] += MC[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        acc[k] = v;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) red[wave][k] = acc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 27) {
-        double s = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < BLOCK / 64; ++w) s += red[w][threadIdx.x];
-        partial[(size_t)c * 27 + threadIdx.x] = s;
-    }
 }
 
 // ------------------------------------------------------------------ peer-store camera exchange --
@@ -827,52 +542,6 @@ GBP_DEV bool peer_wait_row(const PeerWait &wait, int n_parts, int C, int c, int 
     return ok;
 }
 
-// Self-test of the peer-store exchange, run by every rank after gbp_ba_peer_connect and before the first sweep (gbp_ba_peer_selftest): ONE
-// wave stores a tagged probe row -- 27 values that depend on (sender, entry, test number) -- into the probe area of EVERY rank's mailbox
-// exactly the way the sweep's rows travel (write-through data stores, s_waitcnt, tag store), then waits for the probe rows of all
-// ranks in its own mailbox and compares every entry.  out[0] |= 1: a rank's row did not arrive in time, |= 2: it arrived with wrong
-// contents; out[1] = the (lowest) rank concerned.  A pair of devices whose mapping, atomics or ordering do not work shows up here, with a
-// name, instead of as a time-out or a wrong belief in the middle of a run.
-GBP_HD double peer_probe_value(int src, int k, unsigned long long seq) { return (double)(((long long)(src + 1) << 20) + ((long long)k << 12) + (long long)(seq & 0xfffu)); }     // (an integer: exact however it is evaluated)
-__global__ __launch_bounds__(64) void k_peer_selftest(PeerOut peer, const double *mine, int rank, long long timeout_ticks, int *out)
-{
-    const int lane = threadIdx.x;
-    for (int r = 0; r < peer.n; ++r)
-        if (lane < 27) peer_store(peer.dst[r] + lane, peer_probe_value(rank, lane, peer.seq));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-        for (int r = 0; r < peer.n; ++r)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer.dst[r] + 27), peer.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    bool arrived = true;
-    if (lane < peer.n) {
-        const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(mine + (size_t)lane * PEER_ROW + 27);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer.seq) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > timeout_ticks) { arrived = false; break; }
-        }
-    }
-    const unsigned long long late = __ballot(!arrived);
-    unsigned long long wrong = 0ull;
-    for (int r = 0; r < peer.n; ++r) {
-        if ((late >> r) & 1ull) continue;
-        const bool bad = lane < 27 && peer_load(mine + (size_t)r * PEER_ROW + lane) != peer_probe_value(r, lane, peer.seq);
-        if (__ballot(bad)) wrong |= 1ull << r;
-    }
-    if (lane == 0 && (late | wrong)) {
-        out[0] = (late ? 1 : 0) | (wrong ? 2 : 0);
-        out[1] = __ffsll((long long)(late | wrong)) - 1;
-    }
-}
-
-// general path / update_all_beliefs: the partial sums already sit in `partial` (C*27): one wave per camera moves its row
-__global__ __launch_bounds__(BLOCK) void k_peer_push(const double *__restrict__ partial, int C, PeerOut peer)
-{
-    const int lane = threadIdx.x & 63, c = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (c >= C) return;                                     // whole wave
-    peer_push_row(peer, c, lane < 27 ? partial[(size_t)c * 27 + lane] : 0.0, lane);
-}
-
 // belief_c = prior_c + sum over parts (fixed order) of part_r[c]; mu_c = Lambda^-1 eta.  One wavefront per camera: lane k < 27
 // adds entry k of the parts (coalesced 216-byte rows) in rank order, lane 0 collects the 27 sums and solves the 6x6.
 // With wait.src the parts are rows of a mailbox half: the camera's wave polls the n_parts tags of its row first (one lane per rank).
@@ -897,79 +566,6 @@ GBP_DEV void cam_finish_wave(const Params &p, const double *gathered, int n_part
     cam_belief_store(v, p.cbel + (size_t)c * CAMREC, lane);
 }
 
-constexpr int FINISH_BLOCK = 256;
-__global__ __launch_bounds__(FINISH_BLOCK) void k_cam_finish(Params p, const double *gathered, int n_parts, size_t part_stride, PeerWait wait)
-{
-    if (wait.clk && blockIdx.x == 0 && threadIdx.x == 0) *wait.clk = (unsigned long long)wall_clock64();
-    const int lane = threadIdx.x & 63, c = blockIdx.x * (FINISH_BLOCK / 64) + (threadIdx.x >> 6);
-    if (c >= p.C) return;                                   // whole wave
-    cam_finish_wave(p, gathered, n_parts, part_stride, wait, c, lane);
-}
-
-// instrumented runs: one stamp of the device's constant-rate clock (the calibration of gbp_ba_set_kernel_timing)
-__global__ void k_clk_stamp(unsigned long long *out)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out = (unsigned long long)wall_clock64();
-}
-
-// instrumented runs: the stamp ring starts empty
-__global__ void k_clk_init(unsigned long long *clk, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) clk[i] = 0ull;
-}
-
-// ----------------------------------------------------------------------------- diagnostics --
-// Factor.compute_residual at the current belief means (gbp.py:251-259); per-workgroup partial sums of
-// ||r|| (BAFactorGraph.are gbp_ba.py:61-69) and 0.5||r||^2/adaptive_var (FactorGraph.energy gbp.py:36-44).
-__global__ __launch_bounds__(BLOCK) void k_residual(Params p, double *__restrict__ partials)
-{
-    __shared__ double red[BLOCK / 64][2];
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    double nr = 0.0, en = 0.0;
-    int cam, lmk;
-    if (slot < p.T * WTILE && slot_info(p, slot, cam, lmk)) {
-        double x[9], h[2];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) x[k] = p.cbel[(size_t)cam * CAMREC + CAM_MU + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) x[6 + k] = p.lrec[(size_t)lmk * LREC + LR_MU + k];
-        project(x, p.K, h);
-        const double r0 = h[0] - p.lin[lin_at(slot, ROW_Z)], r1 = h[1] - p.lin[lin_at(slot, ROW_Z + 1)];
-        nr = sqrt(r0 * r0 + r1 * r1);
-        const double av = slot_avar(p, slot);
-        en = 0.5 * (nr * nr) / av;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { nr += __shfl_down(nr, off, 64); en += __shfl_down(en, off, 64); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = nr; red[threadIdx.x >> 6][1] = en; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) { a += red[w][0]; b += red[w][1]; }
-        partials[2 * (size_t)blockIdx.x] = a;
-        partials[2 * (size_t)blockIdx.x + 1] = b;
-    }
-}
-
-// ---------------------------------------------------------------------------------- set-up --
-// np.max(factor.factor.lam) per factor at its current linearisation point (gbp_ba.py:31); 0 for empty slots
-__global__ __launch_bounds__(BLOCK) void k_factor_lambda_max(Params p, double *__restrict__ fmax_out)
-{
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot >= p.T * WTILE) return;
-    int cam, lmk;
-    if (!slot_info(p, slot, cam, lmk)) { fmax_out[slot] = 0.0; return; }
-    double x0[9], Jc[2][6], Jl[2][3], h[2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-    linearise(x0, p.K, Jc, Jl, h);
-    const double av = slot_avar(p, slot);
-    fmax_out[slot] = factor_lambda_max(Jc, Jl, 1.0 / av);
-}
-
-// dense (eta_f 9, Lambda_f 81) of a list of slots for the parity views (Factor.factor gbp.py:230,292)
 // Factor.linpoint as the reference would show it: the stored point, or the belief means for a factor whose relinearisation is pending
 GBP_DEV void effective_linpoint(const Params &p, int slot, double (&x0)[9])
 {
@@ -983,255 +579,6 @@ GBP_DEV void effective_linpoint(const Params &p, int slot, double (&x0)[9])
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) x0[k] = p.lin[lin_at(slot, ROW_X0 + k)];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_export_factors(Params p, const int *__restrict__ slots, int n,
-                                                          double *__restrict__ eta_out, double *__restrict__ lam_out)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int slot = slots[i];
-    double x0[9], Jc[2][6], Jl[2][3], h[2], J[2][9], rho[2];
-    effective_linpoint(p, slot, x0);
-    linearise(x0, p.K, Jc, Jl, h);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) J[r][k] = Jc[r][k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) J[r][6 + k] = Jl[r][k];
-    }
-    const double zz[2] = {p.lin[lin_at(slot, ROW_Z)], p.lin[lin_at(slot, ROW_Z + 1)]};
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc += J[r][k] * x0[k];
-        rho[r] = acc + zz[r] - h[r];
-    }
-    const double s = 1.0 / slot_avar(p, slot);
-#pragma unroll
-    for (int a = 0; a < 9; ++a) {
-        eta_out[(size_t)i * 9 + a] = s * (J[0][a] * rho[0] + J[1][a] * rho[1]);
-#pragma unroll
-        for (int b = 0; b < 9; ++b) lam_out[(size_t)i * 81 + a * 9 + b] = s * (J[0][a] * J[0][b] + J[1][a] * J[1][b]);
-    }
-}
-
-// linearisation point / measurement of a list of slots (Factor.linpoint gbp.py:231, Factor.measurement gbp.py:233)
-__global__ __launch_bounds__(BLOCK) void k_export_lin(Params p, const int *__restrict__ slots, int n, double *__restrict__ x0_out,
-                                                      double *__restrict__ z_out)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int slot = slots[i];
-    if (x0_out) {
-        double x0[9];
-        effective_linpoint(p, slot, x0);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x0_out[(size_t)i * 9 + k] = x0[k];
-    }
-    if (z_out) { z_out[(size_t)i * 2] = p.lin[lin_at(slot, ROW_Z)]; z_out[(size_t)i * 2 + 1] = p.lin[lin_at(slot, ROW_Z + 1)]; }
-}
-
-// relinearisation / robust state of a list of slots (gbp.py:242-249): iters_since_relin, flags (bit 0 damped, bit 1 robust),
-// adaptive variance
-__global__ __launch_bounds__(BLOCK) void k_export_relin(Params p, const int *__restrict__ slots, int n, int *__restrict__ iters,
-                                                        unsigned char *__restrict__ flags, double *__restrict__ avar)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int slot = slots[i], st = slot_state(p, slot);
-    if (iters) iters[i] = state_age(st, p.clk);
-    if (flags) flags[i] = (unsigned char)(st & 3);
-    if (avar) avar[i] = slot_avar(p, slot);
-}
-
-// iters_since_relin of a list of slots (ba.py:91-93 per factor), clamped to the counter's range
-__global__ __launch_bounds__(BLOCK) void k_import_iters(Params p, const int *__restrict__ slots, int n, const int *__restrict__ iters)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int slot = slots[i];
-    const int v = min(max(iters[i], 0), ITERS_MAX);
-    set_slot_state(p, slot, state_set_age(slot_state(p, slot), v, p.clk));
-}
-
-// number of factors whose iters_since_relin is 0 (the loop of ba.py:96-99), one atomic per workgroup
-__global__ __launch_bounds__(BLOCK) void k_count_relin(Params p, int *__restrict__ out)
-{
-    __shared__ int red[BLOCK / 64];
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    int cam, lmk;
-    const bool hit = slot < p.T * WTILE && slot_info(p, slot, cam, lmk) && state_age(slot_state(p, slot), p.clk) == 0;
-    const unsigned long long b = __ballot(hit);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int s = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) s += red[w];
-        if (s) atomicAdd(out, s);
-    }
-}
-
-// ---------------------------------------------------------------- stage-wise entry points --
-// The reference lets a caller run the stages of a sweep one by one (gbp.py:46-84).  robustify and the relinearisation DECISION
-// are state-word / variance updates; the relinearisation itself is deferred to the next message computation (state word header).
-
-// FactorGraph.robustify_all_factors (gbp.py:82-84 -> Factor.robustify_loss gbp.py:296-332): the adaptive variance and the robust
-// flag from the residual at the linearisation point; eta_f / Lambda_f are rebuilt from (x0, z, variance) wherever they are needed.
-template <int LOSS>
-__global__ __launch_bounds__(BLOCK) void k_stage_robustify(Params p)
-{
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    int cam, lmk;
-    if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
-    double x0[9], h0[2];
-    effective_linpoint(p, slot, x0);
-    project(x0, p.K, h0);
-    int st = slot_state(p, slot);
-    bool robust = (st & 2) != 0;
-    const double avar = robust_variance(LOSS, p.sigma2, p.nstds, p.lin[lin_at(slot, ROW_Z)] - h0[0], p.lin[lin_at(slot, ROW_Z + 1)] - h0[1], robust);
-    p.avar[slot] = avar;
-    set_slot_state(p, slot, (st & ~2) | (robust ? 2 : 0));
-}
-
-// FactorGraph.relinearise_factors (gbp.py:64-80), or with mark_all FactorGraph.compute_all_factors (gbp.py:60-62: every factor,
-// counters and damping untouched): the decision and its bookkeeping; the move itself is deferred (STATE_PENDING).
-__global__ __launch_bounds__(BLOCK) void k_stage_relinearise(Params p, int mark_all)
-{
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    int cam, lmk;
-    if (slot >= p.T * WTILE || !slot_info(p, slot, cam, lmk)) return;
-    int st = slot_state(p, slot);
-    if (mark_all) { set_slot_state(p, slot, st | STATE_PENDING); return; }
-    int iters = state_age(st, p.clk - 1);                    // (the host has advanced the clock for this call)
-    bool damped = (st & 1) != 0, pending = (st & STATE_PENDING) != 0;
-    double d2 = 0.0;
-    if (!pending) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { const double d = p.lin[lin_at(slot, ROW_X0 + k)] - p.cbel[(size_t)cam * CAMREC + CAM_MU + k]; d2 += d * d; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const double d = p.lin[lin_at(slot, ROW_X0 + 6 + k)] - p.lrec[(size_t)lmk * LREC + LR_MU + k]; d2 += d * d; }
-    }
-    if (!pending && sqrt(d2) > p.beta && iters >= p.min_linear) { iters = 0; damped = false; pending = true; }
-    else iters = min(iters + 1, ITERS_MAX);
-    const int st_new = state_pack(iters, p.clk, state_rank(st), (st & 2) != 0, damped, pending);
-    if (st_new != st) set_slot_state(p, slot, st_new);
-}
-
-// How many factors would be DAMPED in the very message computation that moves their linearisation point -- a pending relinearisation
-// (stage-wise relinearise_factors / compute_all_factors) met by a non-zero eta damping -- if the messages were computed now with
-// these flags?  Such a message has a part outside the span of the new Jacobian, which only the dense remainder (Params::xtra) can
-// carry; the host allocates it when this count is non-zero (gbp_capi.hip: enable_remainder).  Mirrors factor_decide.
-__global__ __launch_bounds__(BLOCK) void k_count_pending_damped(Params p, int local_relin, int no_test, int *__restrict__ out)
-{
-    const int slot = blockIdx.x * BLOCK + threadIdx.x;
-    int cam, lmk;
-    bool hit = false;
-    if (slot < p.T * WTILE && slot_info(p, slot, cam, lmk)) {
-        const int st = slot_state(p, slot);
-        if (st & STATE_PENDING) {
-            int iters = state_age(st, p.clk);
-            if (local_relin && !no_test) iters = min(iters + 1, ITERS_MAX);      // (a pending factor is not tested again: distance 0)
-            const bool damped = (st & 1) != 0 || (local_relin && iters == p.num_undamped);
-            hit = local_relin ? damped : true;
-        }
-    }
-    const unsigned long long b = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
-}
-
-// entries of the dense remainder that are not exactly zero (when none is left the handle returns to the fused sweep)
-__global__ __launch_bounds__(BLOCK) void k_count_nonzero(const double *__restrict__ x, size_t n, int *__restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    const unsigned long long b = __ballot(i < n && x[i] != 0.0);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
-}
-
-// meas_fn / jac_fn of the reprojection factor at n free-standing points (reprojection.py:12-44): the unit the parity
-// tests pin against fixture G1 -- the same `linearise` every sweep kernel inlines
-__global__ __launch_bounds__(BLOCK) void k_eval_fn(Intrinsics K, int n, const double *__restrict__ x, double *__restrict__ h_out,
-                                                   double *__restrict__ J_out, double *__restrict__ hproj_out)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    double x9[9], Jc[2][6], Jl[2][3], h[2], hp[2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) x9[k] = x[(size_t)i * 9 + k];
-    linearise(x9, K, Jc, Jl, h);
-    project(x9, K, hp);
-    if (h_out) { h_out[(size_t)i * 2] = h[0]; h_out[(size_t)i * 2 + 1] = h[1]; }
-    if (hproj_out) { hproj_out[(size_t)i * 2] = hp[0]; hproj_out[(size_t)i * 2 + 1] = hp[1]; }
-    if (J_out) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) J_out[(size_t)i * 18 + r * 9 + k] = Jc[r][k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) J_out[(size_t)i * 18 + r * 9 + 6 + k] = Jl[r][k];
-        }
-    }
-}
-
-// dense messages of a list of slots for the parity views (Factor.messages gbp.py:222): eta 6 | Lambda 21 packed | eta 3 | Lambda 6 packed
-__global__ __launch_bounds__(BLOCK) void k_export_messages(Params p, const int *__restrict__ slots, int n, double *__restrict__ out)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    double eC[6], MC[21], eL[3], ML[6];
-    dense_messages(p, slots[i], eC, MC, eL, ML);
-    double *o = out + (size_t)i * 36;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = eC[k];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) o[6 + k] = MC[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) o[27 + k] = eL[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[30 + k] = ML[k];
-}
-
-// Sigma = Lambda^-1 for the covariance view (VariableNode.Sigma gbp.py:192)
-// mu of every variable, cameras then landmarks, dense: the viewer's per-frame read (vis/ba_vis.py:39-43, 111-114)
-__global__ __launch_bounds__(BLOCK) void k_pack_means(Params p, double *__restrict__ out)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < p.C * 6) out[i] = p.cbel[(size_t)(i / 6) * CAMREC + CAM_MU + i % 6];
-    else if (i < p.C * 6 + p.L * 3) { const int j = i - p.C * 6; out[i] = p.lrec[(size_t)(j / 3) * LREC + LR_MU + j % 3]; }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_covariances(Params p, double *__restrict__ cam_sig, double *__restrict__ lmk_sig)
-{
-    const int v = blockIdx.x * BLOCK + threadIdx.x;          // (the beliefs carry their covariances: gbp_math.hpp, covariance form)
-    if (v < p.C) {
-#pragma unroll
-        for (int k = 0; k < 21; ++k) cam_sig[(size_t)v * 21 + k] = p.cbel[(size_t)v * CAMREC + CAM_COV + k];
-    } else if (v < p.C + p.L) {
-        const int l = v - p.C;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) lmk_sig[(size_t)l * 6 + k] = p.lrec[(size_t)l * LREC + LR_COV + k];
-    }
-}
-
-// BAFactorGraph.weaken_priors (gbp_ba.py:36-42): prior eta and Lambda of every variable times `factor`
-__global__ __launch_bounds__(BLOCK) void k_weaken_priors(Params p, double factor)
-{
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    const size_t nc = (size_t)p.C * 27, nl = (size_t)p.L * 9;
-    if (i < nc) p.cprior[i] *= factor;
-    else if (i < nc + nl) {
-        const size_t j = i - nc;
-        p.lrec[(j / 9) * LREC + LR_PRIOR + (j % 9)] *= factor;
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_fill_iters(Params p, int n, int iters)
-{
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) set_slot_state(p, i, state_set_age(slot_state(p, i), min(max(iters, 0), ITERS_MAX), p.clk));
 }
 
 }  // namespace gbp

@@ -12,9 +12,10 @@ EXTRA = os.environ.get('PHASE_DEFS', '').split()
 NAMES = ['ticket+descriptor', 'issue stream loads', 'lmk beliefs of prev tile (LDS)', 'wait streams', 'camera gather', 'lmk records via LDS',
          'maths', 'stores issued', 'wait accumulation turn', 'accumulate + loop', 'wait for the other waves at the end', 'table write-out']
 if not os.path.exists(LIB) or '--build-only' in sys.argv:
-    csrc = os.path.join(REPO, 'gbp_amd', 'csrc')
-    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast', '-DGBP_PHASE_TIMING'] + EXTRA + [
-                           '-o', LIB, 'gbp_capi.hip', 'gbp_lin_capi.hip', 'gbp_sort.hip'], cwd=csrc)
+    sys.path.insert(0, REPO)
+    from gbp_amd import build
+    build.build(force=True, out=LIB, defines=['GBP_PHASE_TIMING'] + [d[2:] for d in EXTRA if d.startswith('-D')],
+                extra_flags=[d for d in EXTRA if not d.startswith('-D')])
     if '--build-only' in sys.argv:
         sys.exit(0)
 os.environ['GBP_HIP_LIB'] = LIB

@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 # (the switches exist only in a library built with -DGBP_FUSED_DBG_SWITCHES: a scratch copy)
-(cd gbp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=fast -DGBP_FUSED_DBG_SWITCHES -o "$ROOT/tools/libgbp_dbg.so" gbp_capi.hip gbp_lin_capi.hip gbp_sort.hip 2> /dev/null)
+python -m gbp_amd.build --out "$ROOT/tools/libgbp_dbg.so" -DGBP_FUSED_DBG_SWITCHES > /dev/null
 export GBP_HIP_LIB="$ROOT/tools/libgbp_dbg.so"
 for dbg in "$@"; do
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -30,7 +30,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU
   echo "sq group $i ($grp) rc=$?"
 done
 # the ablation switches are compiled out of the product kernel (run-time tests cost it 1.5 us per sweep): a scratch copy of the library has them
-(cd gbp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=fast -DGBP_FUSED_DBG_SWITCHES -o "$ROOT/tools/libgbp_dbg.so" gbp_capi.hip gbp_lin_capi.hip gbp_sort.hip 2> /dev/null)
+python -m gbp_amd.build --out "$ROOT/tools/libgbp_dbg.so" -DGBP_FUSED_DBG_SWITCHES > /dev/null
 for dbg in 0 1 4 5 8 12 14; do
   GBP_HIP_LIB="$ROOT/tools/libgbp_dbg.so" GBP_FUSED_DBG=$dbg timeout 300 $B --steps 200 --warmup 20 > $OUT/bench_dbg$dbg.json 2> $OUT/bench_dbg$dbg.err
 done

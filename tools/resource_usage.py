@@ -9,9 +9,7 @@ REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, REPO)
 from gbp_amd import build
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
-cmd = [build.hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=fast',
-       '-Rpass-analysis=kernel-resource-usage', '-o', '/tmp/_usage.so'] + build.SOURCES
-err = subprocess.run(cmd, cwd=build.CSRC, stderr=subprocess.PIPE, text=True).stderr
+_, err = build.build(force=True, out='/tmp/_usage.so', extra_flags=['-Rpass-analysis=kernel-resource-usage'], capture=True)
 rows = {}
 for blk in re.split(r'remark: Function Name: ', err)[1:]:
     name = blk.split()[0]
