@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_emit(const int *__restrict__ lpt
     if (t < 0) return;                                  // inside somebody else's tile
     const int deg = lptr[l + 1] - lptr[l];
     if (deg > WTILE) {
-        for (int o = 0, c = 0; o < deg; o += WTILE, ++c) tiles[t + c] = make_int4(l, 0, min(WTILE, deg - o), 0);
+        for (int o = 0, c = 0; o < deg; o += WTILE, ++c) tiles[t + c] = make_int4(l, 1, min(WTILE, deg - o), 0);      // chunk tiles: a piece of l and nothing else
         lrow0[l] = t * WTILE; lrow1[l] = t * WTILE + deg;      // chunk tiles are full except the last: the slots are contiguous
         big_list[atomicAdd(big_count, 1)] = l;
         return;
@@ -174,8 +174,49 @@ __global__ __launch_bounds__(BLOCK) void k_pack_emit(const int *__restrict__ lpt
     }
 }
 
+// ---- dense packing: tile t = factors [64 t, 64 t + 64) of the landmark-major list (landmarks may span tiles) --------------------------
+// Whole-landmark tiles leave slots empty when the landmarks are large -- 40 factors each: one landmark and 24 idle lanes per tile --
+// and every idle lane costs what a busy one does in the sweep's memory pipeline.  When every landmark has at least three factors a
+// 64-factor window touches at most 22 landmarks (TILE_LMKS = 24 holds), so the windows themselves can be the tiles; the parts of the
+// landmarks they cut are summed per tile and finished by k_lmk_finish_parts (gbp_kernels.hpp).  The host picks this packing when the
+// whole-landmark one would fill less than 85 % of the slots (gbp_capi.hip: build_graph).
+__global__ __launch_bounds__(BLOCK) void k_min_degree(const int *__restrict__ lptr, int L, int *__restrict__ out)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    int d = l < L ? lptr[l + 1] - lptr[l] : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = min(d, __shfl_down(d, off, 64));
+    if ((threadIdx.x & 63) == 0 && d != 0x7fffffff) atomicMin(out, d);
+}
+
+// the landmark that holds position `pos` of the landmark-major list (no landmark is empty here)
+GBP_DEV int landmark_of_position(const int *__restrict__ lptr, int L, int pos)
+{
+    int lo = 0, hi = L;                                  // largest l with lptr[l] <= pos
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lptr[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_dense_tiles(const int *__restrict__ lptr, int L, int F, int T, int4 *__restrict__ tiles)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const int p0 = t * WTILE, p1 = min(F, p0 + WTILE) - 1;
+    const int l0 = landmark_of_position(lptr, L, p0), l1 = landmark_of_position(lptr, L, p1);
+    tiles[t] = make_int4(l0, l1 - l0 + 1, p1 - p0 + 1, 0);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_dense_rows(const int *__restrict__ lptr, int L, int *__restrict__ lrow0, int *__restrict__ lrow1)
+{
+    const int l = blockIdx.x * BLOCK + threadIdx.x;
+    if (l < L) { lrow0[l] = lptr[l]; lrow1[l] = lptr[l + 1]; }
+}
+
 struct BuildArgs {
-    int4 *tiles;                          // in: {first landmark, landmarks owned, slots used, -}; out: .w = max rank
+    int4 *tiles;                          // in: {first landmark, landmarks it holds (parts of) , slots used, -}; out: .w = max rank
     const int *lrow0, *lptr;              // per landmark: first slot; offsets into lm2ref
     const int *lm2ref, *ref_cam, *ref_file;   // ref_file may be NULL (reference order == file order)
     const double *cam_means, *lmk_means, *meas;
@@ -193,11 +234,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
     const bool active = lane < td.z;
     int cam = -1 - lane, l = td.x, r = 0;       // inactive lanes: distinct negative "cameras" that match nobody
     if (active) {
-        if (td.y > 0) {
-            int k = 0;
-            for (int i = 1; i < td.y; ++i) k += (a.lrow0[td.x + i] <= slot) ? 1 : 0;     // rows ascend with the landmark
-            l = td.x + k;
-        }
+        int k = 0;
+        for (int i = 1; i < td.y; ++i) k += (a.lrow0[td.x + i] <= slot) ? 1 : 0;         // rows ascend with the landmark
+        l = td.x + k;
         r = a.lm2ref[a.lptr[l] + (slot - a.lrow0[l])];
         cam = a.ref_cam[r];
     }
@@ -212,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mr = max(mr, __shfl_down(mr, off, 64));
     if (lane == 0) a.tiles[t].w = mr;
-    slot_words(p, slot)[0] = active ? (((unsigned)cam << META_LMK_BITS) | (unsigned)(td.y > 0 ? l - td.x : 0)) : 0u;
+    slot_words(p, slot)[0] = active ? (((unsigned)cam << META_LMK_BITS) | (unsigned)(l - td.x)) : 0u;
     set_slot_state(p, slot, state_pack(1, p.clk, active ? rank : 0, false, false));      // iters_since_relin = 1, gbp.py:249
     if (p.avar) p.avar[slot] = p.sigma2;                                                 // gbp.py:242
     a.cpos[slot] = active ? r : 0;

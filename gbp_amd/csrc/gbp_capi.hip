@@ -187,25 +187,46 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
                            n_nodes);
     hipLaunchKernelGGL(k_pack_block_fill, dim3(grid_for((size_t)n_pblocks)), dim3(BLOCK), 0, h->stream, nxt, w0, L, n_pblocks, bpos, pos);
     HIPCHK(hipGetLastError());
-    int T = 0;
+    int T = 0, min_deg = 0x7fffffff, *d_mindeg = nullptr;
+    CHK(scratch_alloc(h, scratch, &d_mindeg, 1));
+    HIPCHK(hipMemcpyAsync(d_mindeg, &min_deg, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (L) hipLaunchKernelGGL(k_min_degree, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, d_mindeg);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&T, pos + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&min_deg, d_mindeg, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (L == 0) T = 0;
+    // Whole landmarks per tile (T tiles from the list ranking above), or -- when that would leave more than 15 % of the slots empty
+    // and every landmark has at least three factors -- the dense packing: tile t = factors [64 t, 64 t + 64), landmarks may span tiles
+    // (gbp_build.hpp).  One million factors at 40 per landmark: 25 000 tiles of 40 -> 15 625 full ones.  GBP_PACK=whole|dense overrides
+    // (tests, A/B runs); "dense" still needs the three factors per landmark.
+    bool dense = false;
+    if (T > 0 && F > 0 && min_deg >= 3) {
+        const char *e = getenv("GBP_PACK");
+        dense = e ? strcmp(e, "dense") == 0 : (double)F < 0.85 * 64.0 * (double)T;
+    }
+    if (dense) T = (F + WTILE - 1) / WTILE;
     if (T < 0 || (int64_t)T * WTILE > INT32_MAX) return fail(GBP_EINVAL, "the graph needs %d tiles: slot indices would not fit 32 bits", T);
     const size_t S = std::max<size_t>((size_t)T * WTILE, 1);
     p.T = T;
     int4 *d_tiles = nullptr;
     CHK(dev_alloc(h, &d_tiles, std::max<size_t>((size_t)T, 1)));
-    if (L) hipLaunchKernelGGL(k_pack_emit, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, nxt, pos, d_tiles, d_lrow0, d_lrow1,
-                              d_big_list, d_cnt);
-    HIPCHK(hipGetLastError());
     int n_big = 0;
-    HIPCHK(hipMemcpyAsync(&n_big, d_cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (n_big) {
-        CHK(download(h, h->big_lmks, d_big_list, (size_t)n_big));
-        std::sort(h->big_lmks.begin(), h->big_lmks.end());                        // (the kernel appends them in any order)
+    if (dense) {
+        hipLaunchKernelGGL(k_dense_tiles, dim3(grid_for((size_t)T)), dim3(BLOCK), 0, h->stream, lptr, L, F, T, d_tiles);
+        hipLaunchKernelGGL(k_dense_rows, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, d_lrow0, d_lrow1);
+        HIPCHK(hipGetLastError());
+    } else {
+        if (L) hipLaunchKernelGGL(k_pack_emit, dim3(grid_for((size_t)L)), dim3(BLOCK), 0, h->stream, lptr, L, nxt, pos, d_tiles, d_lrow0, d_lrow1,
+                                  d_big_list, d_cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&n_big, d_cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
     }
+    // 0: every landmark inside one tile; 1: whole landmarks, those above 64 factors in chunk tiles; 2: dense.  From 1 on some landmarks span
+    // tiles: the tiles write partial sums (Params::parts) and k_lmk_finish_parts forms those beliefs after every sweep.
+    h->pack_mode = dense ? 2 : (n_big ? 1 : 0);
+    h->n_big = n_big;
 
     clk.mark("tile packing");
     // 5. per-slot data
@@ -228,7 +249,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
                           + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
                           + (size_t)std::max(C, 1) * (CAMREC + CBEL + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
-                          + (size_t)(n_wg + 1 + h->big_lmks.size()) * sizeof(int) + (64 << 12);
+                          + (size_t)(n_wg + 1) * sizeof(int) + (h->pack_mode ? 2 * (size_t)std::max(T, 1) * PART_ROW * sizeof(double) : 0) + (64 << 12);
         CHK(arena_reserve(h, need));
     }
     if (general_sweep && F > 0) { CHK(dev_alloc(h, &p.cstage, Fz * p.crow)); h->cstage_cap = p.crow; }   // out of the same arena (else: on first use, ensure_staging)
@@ -237,6 +258,7 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     if (p.loss != 0) CHK(dev_alloc(h, &p.avar, S));         // adaptive variances: robust losses only
     CHK(dev_alloc(h, &cpos, S));
     CHK(dev_alloc(h, &p.lrec, (size_t)std::max(L, 1) * LREC));
+    if (h->pack_mode) CHK(dev_alloc(h, &p.parts, 2 * (size_t)std::max(T, 1) * PART_ROW));
     CHK(dev_alloc(h, &p.cbel, (size_t)std::max(C, 1) * CAMREC)); CHK(dev_alloc(h, &p.cprior, (size_t)std::max(C, 1) * 27));
     CHK(dev_alloc(h, &p.cbelief, (size_t)std::max(C, 1) * CBEL));
     p.tiles = d_tiles; p.cptr = cptr; p.cadj = cadj; p.cpos = cpos;
@@ -527,7 +549,7 @@ int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n)
     const int32_t v[GBP_PLAN_INFO_FIELDS] = {
         h->fused.enabled ? 1 : 0, h->staged_auto ? 1 : 0, h->fused.enabled ? h->fused.single : 0, h->fused.single_probe,
         pinned ? h->fused.args.pin : -1, h->fused.enabled ? h->fused.n_blocks : std::max(1, std::min(h->p.T, h->n_cus)), h->p.T,
-        (int32_t)h->big_lmks.size()};
+        h->pack_mode};
     for (int i = 0; i < n && i < GBP_PLAN_INFO_FIELDS; ++i) out[i] = v[i];
     return GBP_OK;
 }

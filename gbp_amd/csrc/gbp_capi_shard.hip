@@ -255,7 +255,7 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
     po.n = n; po.seq = pe.seq;
     for (int r = 0; r < n; ++r) po.dst[r] = peer_data(h, pe.base[r], n, half, pe.rank);
     PeerWait w{peer_data(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1, nullptr};
-    const bool big = with_messages && !h->big_lmks.empty();
+    const bool big = with_messages && h->p.parts != nullptr;
     // Without a rendezvous hook everything behind the fused sweep is ONE launch (k_cam_reduce_xchg); logical ranks on one device
     // (the hook is set) keep reduce / push and finish apart, with the hook between them, so that they never spin on each other.
     const bool merged = !h->xch_fn && with_messages && h->fused.enabled && !getenv("GBP_PEER_SPLIT");
@@ -269,7 +269,7 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
         }
         HIPCHK(hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-        CHK(launch_big_lmk_beliefs(h, h->side_stream));
+        CHK(launch_finish_parts(h, h->side_stream));
         HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
     }
     if (!finished) {
@@ -293,7 +293,7 @@ static int sharded_step(gbp_ba *h, int with_messages, int robustify, int local_r
         if (!finished) CHK(launch_cam_finish(h, h->d_partial, 1, 0));
         return GBP_OK;
     }
-    const bool big = with_messages && !h->big_lmks.empty();     // their beliefs need nothing from the exchange: side stream
+    const bool big = with_messages && h->p.parts != nullptr;     // landmarks that span tiles: their beliefs need nothing from the exchange: side stream
     CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, nullptr, big));
     if (big) {
         if (!h->side_stream) {
@@ -303,7 +303,7 @@ static int sharded_step(gbp_ba *h, int with_messages, int robustify, int local_r
         }
         HIPCHK(hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-        CHK(launch_big_lmk_beliefs(h, h->side_stream));
+        CHK(launch_finish_parts(h, h->side_stream));
         HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
     }
     int rc = h->xch_fn(h->xch_ctx, h->d_send, h->d_recv, (uint64_t)h->p.C * 27, h->stream);

@@ -9,7 +9,7 @@
 #include <cmath>
 #include <thread>
 
-int gbp::plan_fused_sweep(gbp_ba *h, int n_cus) { return fused_plan(h->fused, h->p, h->big_lmks, h->stream, n_cus); }
+int gbp::plan_fused_sweep(gbp_ba *h, int n_cus) { return fused_plan(h->fused, h->p, h->stream, n_cus); }
 int gbp::fused_max_cams_of_this_build() { return fused_max_cams(); }
 
 // ------------------------------------------------------------------------------ launches --
@@ -103,19 +103,13 @@ static int ensure_staging(gbp_ba *h)
         h->cstage_cap = h->p.crow;
         h->cstage_x0_ok = false;
     }
-    if (!h->big_lmks.empty() && !h->d_big) {
-        CHK(dev_alloc(h, &h->d_big, h->big_lmks.size(), false));
-        CHK(upload(h, h->d_big, h->big_lmks));
-    }
     return GBP_OK;
 }
 
-int gbp::launch_big_lmk_beliefs(gbp_ba *h, hipStream_t stream)
+int gbp::launch_finish_parts(gbp_ba *h, hipStream_t stream)
 {
-    const int *list = h->fused.enabled ? h->fused.d_big : h->d_big;
-    const int n = (int)h->big_lmks.size();
-    if (!n || !list) return GBP_OK;
-    hipLaunchKernelGGL(k_lmk_belief_list, dim3((n + 63) / 64), dim3(64), 0, stream, h->p, list, n);
+    if (!h->p.parts || !h->p.T) return GBP_OK;
+    hipLaunchKernelGGL(k_lmk_finish_parts, dim3(grid_for((size_t)h->p.T)), dim3(BLOCK), 0, stream, h->p);
     HIPCHK(hipGetLastError());
     return GBP_OK;
 }
@@ -129,8 +123,8 @@ static int launch_peer_push(gbp_ba *h, const double *partial, const PeerOut &pee
     return GBP_OK;
 }
 
-// defer_big: leave the beliefs of the over-sized landmarks (k_lmk_belief_list) to the caller, who runs them beside the
-// camera exchange (launch_big_lmk_beliefs)
+// defer_big: leave the beliefs of the landmarks that span tiles (k_lmk_finish_parts) to the caller, who runs them beside the
+// camera exchange (launch_finish_parts)
 int gbp::sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish, bool *finished, bool defer_big,
                      const PeerOut *peer, const PeerWait *merged)
 {
@@ -185,7 +179,7 @@ int gbp::sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_reli
             CHK(time_end(h));
             if (rc != 0) return fail(GBP_EHIP, "general sweep launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
-        if (!defer_big) CHK(launch_big_lmk_beliefs(h, h->stream));
+        if (!defer_big) CHK(launch_finish_parts(h, h->stream));
         if (h->p.C) {
             // One workgroup per camera.  Short runs (a camera with a few hundred factors: graphs with thousands of cameras) leave most
             // of a 256-thread block idle through its reduction and 6x6 solve: 128 threads do 1M factors x 2 000 / 3 000 cameras in

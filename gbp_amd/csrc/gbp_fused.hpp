@@ -48,8 +48,8 @@
 // ordered section into three (nine entries each, a turn counter per third, so that three waves can be inside): 84.7 against
 // 79.5 us per step -- the ordered section is not what the waves queue for, two more hand-overs per tile only cost.
 //
-// Landmarks with more than 64 factors do not fit a tile: their factors form chunk tiles (nl = 0: messages only)
-// and their beliefs are formed afterwards by k_lmk_belief_list.  If acc + the per-wave scratch do not fit the LDS
+// Landmarks that span tiles (more than 64 factors: chunk tiles; or the dense packing, gbp_kernels.hpp header): every tile adds up its
+// part of their messages, and their beliefs are formed afterwards by k_lmk_finish_parts.  If acc + the per-wave scratch do not fit the LDS
 // (C > 516) the cameras are split into two groups (516 + up to 758): the sweep adds up the first, k_cam_pass the others; beyond that the
 // plan stays disabled and the general sweep runs.
 #pragma once
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     // scratch, which the next tile overwrites only afterwards; the priors they are added to (one entry per lane and pass) and the
     // landmarks' slot ranges are fetched with the tile's own streams and wait in nine registers.
     bool pend = false;
-    int q_l0 = 0, q_nl = 0;
+    int q_t = 0, q_l0 = 0, q_nl = 0;
     LmkPre pre;
 #pragma unroll
     for (int b = 0; b < LMK_PASSES; ++b) pre.pri[b] = 0.0;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         const int t = tb + (valid ? (a.reverse ? ntl - 1 - ti : ti) : 0);
         GBP_PH(0);                                         // ticket
         if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
-            if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
+            if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_t, q_l0, q_nl, pre);
             GBP_PH_NOWAIT(2);
             break;
         }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         const int4 td = tiles[t];
         const int l0 = td.x, nl = td.y, nf = td.z, maxrank = td.w;
         const bool active = lane < nf;
-        const int nhead2 = max(nl, 1) * (LHEAD / 2);       // in 16-byte pieces; chunk tiles stage the over-sized landmark td.x
+        const int nhead2 = nl * (LHEAD / 2);               // in 16-byte pieces (a chunk tile: the one landmark it holds a piece of)
         const double2 *lsrc = reinterpret_cast<const double2 *>(p.lrec + (size_t)l0 * LREC);
         constexpr int NSTAGE = (TILE_LMKS * (LHEAD / 2) + 63) / 64;
         double2 stage[NSTAGE];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         GBP_PH_NOWAIT(1);                                  // issue of the stream loads
 
         // ---- tail of the previous tile: its landmark beliefs = prior + messages in adj_factors order (gbp.py:182-193)
-        if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_l0, q_nl, pre);
+        if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_t, q_l0, q_nl, pre);
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(2);                                  // landmark beliefs of the previous tile (LDS)
 
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
                     reinterpret_cast<double2 *>(p.cstage + (size_t)wpos[f] * CSTAGE_PLAIN)[k2] = reinterpret_cast<const double2 *>(wr + f * CSTAGE_PLAIN)[k2];
             }
             wave_lds_sync();
-            pend = true; q_l0 = l0; q_nl = nl;
+            pend = true; q_t = t; q_l0 = l0; q_nl = nl;
             continue;
         }
         wave_lds_sync();
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         }
         wave_lds_sync();
         if (lane == 0) __hip_atomic_store(&ctl[1], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pend = true; q_l0 = l0; q_nl = nl;
+        pend = true; q_t = t; q_l0 = l0; q_nl = nl;
     }
     if (lane == 0) relin_add(p, n_relin);
     if (STAGED) return;
@@ -552,8 +552,8 @@ inline int single_probe(hipStream_t stream, int *mask)
 // (Rounds 2-3 added the messages to a second group of up to 758 cameras in an extra pass over the stored messages, k_cam_pass: 138.7 us
 //  per sweep at C = 1000.  The general sweep's persistent STAGED form does the same graph in 127 us and has no camera limit: removed.)
 
-// Workgroup tile ranges + per-workgroup camera tables; `big` = landmarks larger than a tile.
-inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t> &big, hipStream_t stream, int n_cus)
+// Workgroup tile ranges + per-workgroup camera tables.
+inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_cus)
 {
     if (p.F == 0 || p.C == 0 || p.T == 0) return 0;
     // the sweep's table shares the LDS with the waves' scratch: more cameras than fit run the general sweep (STAGED form of the same loop)
@@ -567,8 +567,6 @@ inline int fused_plan(FusedPlan &pl, const Params &p, const std::vector<int32_t>
     if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
     double *d_bp = nullptr;                                 // (workgroup b walks tiles [b T / n_blocks, (b + 1) T / n_blocks): computed in the kernels)
     if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * TROW, stream)) return -1;
-    pl.n_big = (int)big.size();
-    if (pl.n_big && fused_upload(pl, &pl.d_big, big.data(), big.size(), stream)) return -1;
     pl.args = FusedArgs{};
     pl.args.block_partials = d_bp; pl.args.acc_doubles = acc_doubles; pl.args.cam_base = 0; pl.args.cam_count = std::min(p.C, pl.group_cams);
 #if defined(GBP_FUSED_DBG_SWITCHES) || defined(GBP_PHASE_TIMING)
@@ -647,7 +645,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
-    if (pl.n_big && !defer_big) hipLaunchKernelGGL(k_lmk_belief_list, dim3((pl.n_big + 63) / 64), dim3(64), 0, stream, p, pl.d_big, pl.n_big);
+    if (p.parts && !defer_big) hipLaunchKernelGGL(k_lmk_finish_parts, dim3((p.T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, p);
     const size_t red_shmem = 0;                             // (static LDS)
     PeerOut po{};
     if (peer) po = *peer;

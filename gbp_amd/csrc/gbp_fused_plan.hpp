@@ -60,14 +60,13 @@ struct FusedArgs {
 struct FusedPlan {
     bool enabled = false;
     int n_groups = 0, group_cams = 0;                // (one camera group: the whole table in LDS)
-    int n_blocks = 0, n_big = 0;
+    int n_blocks = 0;
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
     int single_probe = -1;                           // -1: SINGLE not wanted, no probe; 1: the device's lane order was verified; 0: it failed, rounds variant instead
     int single_probe_mask = 0;                       // failing patterns of k_single_probe
     size_t shmem = 0;
     FusedArgs args{};
-    int *d_big = nullptr;
     std::vector<void *> allocs;
     void *(*alloc)(void *ctx, size_t bytes) = nullptr;   // optional: take device memory from the owner's arena (else hipMalloc)
     void *alloc_ctx = nullptr;

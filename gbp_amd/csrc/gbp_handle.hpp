@@ -51,8 +51,7 @@ struct gbp_ba {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // order maps: on the device (built there, gbp_build.hpp); the host keeps only what is L- or C-sized
     int *d_ref_cam = nullptr, *d_ref_lmk = nullptr;   // per reference factor (p.cadj = reference id -> slot, p.cpos = slot -> reference id)
-    std::vector<int32_t> big_lmks;               // landmarks larger than a tile
-    int *d_big = nullptr;                        // the same on the device (general sweep)
+    int pack_mode = 0, n_big = 0;                // tile packing (build_graph): 0 whole landmarks, 1 + chunk tiles of the n_big landmarks above 64 factors, 2 dense
     bool hash_ok = false; uint64_t hash = 0;     // digest of the layout (state blobs)
     void *arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
     std::vector<void *> snap; std::vector<size_t> snap_bytes; bool snap_has_beliefs = false; uint32_t snap_parity = 0; int snap_clk = 0;   // device-resident checkpoint (gbp_ba_snapshot_state)
@@ -231,7 +230,7 @@ int fused_max_cams_of_this_build();
 int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, double *partial, int finish = 0, bool *finished = nullptr,
                 bool defer_big = false, const PeerOut *peer = nullptr, const PeerWait *merged = nullptr);
 int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, size_t stride, const PeerWait *wait = nullptr);
-int launch_big_lmk_beliefs(gbp_ba *h, hipStream_t stream);
+int launch_finish_parts(gbp_ba *h, hipStream_t stream);      // beliefs of the landmarks that span tiles (after a sweep's factor kernel)
 int launch_peer_selftest(gbp_ba *h, const PeerOut &po, const double *mine, int rank, long long ticks, int *d_out);
 int enable_remainder(gbp_ba *h);
 int remainder_drop(gbp_ba *h);

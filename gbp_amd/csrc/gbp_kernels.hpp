@@ -4,8 +4,12 @@
 // -------------------------------------------------------------------------------------------------
 // Factors live in TILES of 64 slots (one wavefront).  Factors are ordered landmark-major (stable by
 // reference factor id inside a landmark) and a tile owns up to 24 whole landmarks: all factors of those
-// landmarks, nf <= 64 of the 64 slots used.  A landmark with more than 64 factors is cut into "chunk"
-// tiles (nl = 0) that own no landmark.  Slot id = tile*64 + lane.
+// landmarks, nf <= 64 of the 64 slots used.  A landmark may also SPAN tiles -- one with more than 64 factors always does ("chunk"
+// tiles: nl = 1, a piece of that landmark and nothing else), and in the dense packing (graphs whose whole landmarks would leave the
+// tiles under-filled: gbp_capi.hip build_graph) tile t simply holds factors [64 t, 64 t + 64) of the landmark-major list.  A tile that
+// holds only a PART of a landmark adds its part of the messages up and writes the sum to Params::parts (row 2 t: the landmark began
+// in an earlier tile, row 2 t + 1: it goes on in the next); k_lmk_finish_parts forms those beliefs after the sweep.
+// Slot id = tile*64 + lane.
 //
 // Everything a factor streams per sweep is TILE-CONTIGUOUS; inside a tile rows are stored in pairs,
 // [row/2][64 lanes][2], so a lane owns 16 contiguous bytes per pair (one dwordx4 access):
@@ -85,7 +89,10 @@ struct Params {
     int *relin_slot;              // this sweep's "factors that relinearised" counter (ba.py:96-99 without a read-back of F words), or NULL
     int stage;                    // 0: a whole synchronous_iteration.  STAGE_* bits: the reference's stage-wise entry points (gbp.py:46-84)
     int clk, clk_inc;             // the graph's relinearisation clock AFTER this call, and whether this call advances it (state word below)
+    double *parts;                // [2 T][PART_ROW] partial sums (eta 3 | Lambda 6, no prior) of the landmarks that span more than one tile, or
+                                  // NULL when no landmark does (tile_landmark_beliefs writes them, k_lmk_finish_parts adds them up)
 };
+constexpr int PART_ROW = 10;      // doubles per row of Params::parts (9 + pad: rows start on 16 bytes)
 constexpr int STAGE_NO_TEST = 1;      // compute_all_messages alone: no relinearisation test, no iters_since_relin bookkeeping (gbp.py:46-54)
 constexpr int STAGE_NO_BELIEFS = 2;   // ... and no belief is touched (the reference updates them in update_all_beliefs only, gbp.py:56-58)
 
@@ -404,6 +411,7 @@ GBP_DEV void lmk_belief_store(const double (&b)[9], double *__restrict__ lr)
 // each, seven landmarks per pass -- lane (g, k) = (lane / 9, lane % 9) holds prior entry k of landmark 7 b + g for pass b -- and
 // lane l < nl holds landmark l's slot range relative to the tile (two bytes).
 constexpr int LMK_PASSES = (TILE_LMKS + 6) / 7;
+constexpr int ROWS_CONT = 1 << 16, ROWS_MORE = 1 << 17;     // flags beside the two 8-bit slot bounds of LmkPre::rows
 struct LmkPre {
     double pri[LMK_PASSES];
     int rows;
@@ -419,42 +427,85 @@ GBP_DEV void lmk_prefetch(const Params &p, int lane, int t, int l0, int nl, LmkP
     }
     q.rows = 0;
     if (lane < nl) {
+        // the landmark's slots inside THIS tile, and whether it began before it (ROWS_CONT) / goes on behind it (ROWS_MORE)
         const int2 r = *reinterpret_cast<const int2 *>(base + (unsigned)(lane * LREC + LR_ROWS));
-        q.rows = (r.x - t * WTILE) | ((r.y - t * WTILE) << 8);
+        const int a = r.x - t * WTILE, b = r.y - t * WTILE;
+        q.rows = max(a, 0) | (min(b, WTILE) << 8) | (a < 0 ? ROWS_CONT : 0) | (b > WTILE ? ROWS_MORE : 0);
     }
 }
 
 // The landmark beliefs of a tile from the wave's LDS scratch wl = [64][9] new messages (eta 3 | Lambda 6 per factor lane): prior +
-// messages in adj_factors order (gbp.py:182-193), then mean and covariance.  The sums go back into rows of wl that no later pass
-// reads (landmark l's factors sit in lanes >= l), and one lane per landmark solves and writes the record.  (One lane per landmark
+// messages in adj_factors order (gbp.py:182-193), then mean and covariance.  The sums go back into the first rows of wl once every pass
+// has read its messages, and one lane per landmark solves and writes the record.  (One lane per landmark
 // reading 9 doubles per message was the longest phase of the loop: 27 % of the wave-time with 6 of 64 lanes busy.)
-GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int l0, int nl, const LmkPre &q)
+GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int t, int l0, int nl, const LmkPre &q)
 {
     const int g = (lane * 57) >> 9, k = lane - g * 9;
+    double sums[LMK_PASSES];
 #pragma unroll
     for (int b = 0; b < LMK_PASSES; ++b) {
-        if (b * 7 >= nl) break;                             // wave-uniform
+        sums[b] = 0.0;
+        if (b * 7 >= nl) continue;                          // wave-uniform
         const int li = b * 7 + g;
         const int rows = __shfl(q.rows, li, 64);
         if (g < 7 && li < nl) {
-            double acc = q.pri[b];
+            // a landmark that spans tiles: the sum of THIS tile's part alone (the prior joins in k_lmk_finish_parts)
+            double acc = (rows & (ROWS_CONT | ROWS_MORE)) ? 0.0 : q.pri[b];
             int r = rows & 0xff;
-            const int r1 = rows >> 8;
+            const int r1 = (rows >> 8) & 0xff;
             for (; r + 4 <= r1; r += 4) {                   // four reads in flight, the additions in adj_factors order as before
                 const double v0 = wl[r * 9 + k], v1 = wl[(r + 1) * 9 + k], v2 = wl[(r + 2) * 9 + k], v3 = wl[(r + 3) * 9 + k];
                 acc += v0; acc += v1; acc += v2; acc += v3;
             }
             for (; r < r1; ++r) acc += wl[r * 9 + k];
-            wl[li * 9 + k] = acc;
+            sums[b] = acc;
         }
+    }
+    // The sums go back into the scratch only when every pass has read its messages: landmark li's row may still hold the message of a
+    // LATER landmark's factor (landmarks without factors take no slot, so "landmark li's factors sit in lanes >= li" does not hold for
+    // the landmarks behind them; rounds 1-4 wrote inside the pass loop and a tile led by seven or more empty landmarks summed sums).
+    wave_lds_sync();
+#pragma unroll
+    for (int b = 0; b < LMK_PASSES; ++b) {
+        const int li = b * 7 + g;
+        if (b * 7 < nl && g < 7 && li < nl) wl[li * 9 + k] = sums[b];
     }
     wave_lds_sync();
     if (lane < nl) {
         double b[9];
 #pragma unroll
         for (int k2 = 0; k2 < 9; ++k2) b[k2] = wl[lane * 9 + k2];
-        lmk_belief_store(b, p.lrec + (size_t)(l0 + lane) * LREC);
+        if (q.rows & (ROWS_CONT | ROWS_MORE)) {             // (at most the first and the last landmark of a tile)
+            double *dst = p.parts + ((size_t)2 * t + ((q.rows & ROWS_CONT) ? 0 : 1)) * PART_ROW;
+#pragma unroll
+            for (int k2 = 0; k2 < 9; ++k2) dst[k2] = b[k2];
+        } else {
+            lmk_belief_store(b, p.lrec + (size_t)(l0 + lane) * LREC);
+        }
     }
+}
+
+// Beliefs of the landmarks that span tiles, after a sweep: thread t looks at the FIRST landmark of tile t; if it began in an earlier
+// tile and ends in this one, the thread adds up prior + the parts of all its tiles in tile (= adj_factors) order -- row 2 t0 + 1 of
+// the tile it begins in, rows 2 t' of the tiles it continues in (tile_landmark_beliefs) -- and writes mean | covariance
+// (VariableNode.update_belief gbp.py:176-198).  At most one landmark ends that way per tile; no list of them is needed.
+GBP_DEV void finish_landmark_parts(const Params &p, int t)
+{
+    const int4 td = p.tiles[t];
+    if (td.y < 1 || td.z < 1) return;
+    double *lr = p.lrec + (size_t)td.x * LREC;
+    const int2 rows = *reinterpret_cast<const int2 *>(lr + LR_ROWS);
+    if (rows.x >= t * WTILE || rows.y > (t + 1) * WTILE) return;      // did not begin earlier, or goes on: somebody else's
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = lr[LR_PRIOR + k];
+    const int t0 = rows.x / WTILE;
+    for (int tt = t0; tt <= t; ++tt) {
+        const double *src = p.parts + ((size_t)2 * tt + (tt == t0 ? 1 : 0)) * PART_ROW;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] += src[k];
+    }
+    lmk_belief_store(acc, lr);
 }
 
 // ------------------------------------------------------------------ general sweep, stage 2 --

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
     LmkPre pre;
     lmk_prefetch(p, lane, t, l0, nl, pre);
     wave_lds_sync();                                        // the wave's LDS writes are done (one wave: no barrier needed)
-    tile_landmark_beliefs(p, wl, lane, l0, nl, pre);
+    tile_landmark_beliefs(p, wl, lane, t, l0, nl, pre);
     // camera-message rows -> cstage through LDS: a lane-per-factor store would touch 64 different lines per instruction;
     // transposed, whole rows go out, 16 bytes per lane
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // landmark phase has read the [64][9] messages
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
     if (l < p.L) landmark_belief_from_hbm(p, l);
 }
 
-// beliefs of a list of landmarks (the ones larger than a tile, after the fused sweep)
-__global__ __launch_bounds__(64) void k_lmk_belief_list(Params p, const int *__restrict__ list, int n)
+// beliefs of the landmarks that span more than one tile, after a sweep (gbp_kernels.hpp: finish_landmark_parts); one thread per tile
+__global__ __launch_bounds__(BLOCK) void k_lmk_finish_parts(Params p)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i < n) landmark_belief_from_hbm(p, list[i]);
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < p.T) finish_landmark_parts(p, t);
 }
 
 // One workgroup per camera: sum of the messages of its factors (gathered through cadj), WITHOUT the

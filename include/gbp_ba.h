@@ -237,7 +237,10 @@ int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_b
  * by the sparseness rule (few factors per camera and workgroup), not asked for; [2] the fused sweep adds all same-camera lanes of a
  * tile in ONE LDS atomic instruction (the SINGLE variant: graphs of few cameras); [3] the probe of the lane order SINGLE relies on,
  * run at create on the handle's device: 1 passed, 0 failed (the rounds variant runs instead), -1 SINGLE was not wanted; [4] tiles per
- * workgroup that keep using the memory-side cache (-1: all of them); [5] workgroups; [6] tiles; [7] landmarks larger than a tile */
+ * workgroup that keep using the memory-side cache (-1: all of them); [5] workgroups; [6] tiles; [7] tile packing: 0 every landmark
+ * inside one 64-slot tile, 1 the same with the landmarks above 64 factors cut into chunk tiles, 2 dense (tile t = factors [64 t, 64 t + 64)
+ * of the landmark-major list: chosen when whole landmarks would leave more than 15 % of the slots empty and every landmark has at
+ * least three factors).  From 1 on some landmarks span tiles: their beliefs are formed by a small kernel after the sweep. */
 #define GBP_PLAN_INFO_FIELDS 8
 int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n);
 int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols);   /* debug builds with -DGBP_PHASE_TIMING only (tools/phase_profile.py): per-wave time per phase of the last fused sweep */

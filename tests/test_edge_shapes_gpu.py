@@ -142,7 +142,7 @@ def test_single_variant_is_probed_on_the_device_and_falls_back(monkeypatch):
     monkeypatch.delenv('GBP_SINGLE_PROBE_FAIL', raising=False)
     e = BAEngine.from_problem(make_synthetic(n_cams=500, n_lmks=20_000, obs_per_lmk=10, seed=1), fused=True)
     pi = e.plan_info()
-    assert pi['fused'] and not pi['single'] and pi['single_probe'] == -1 and pi['pinned_tiles'] == -1 and pi['n_blocks'] == 256, pi
+    assert pi['fused'] and not pi['single'] and pi['single_probe'] == -1 and pi['pinned_tiles'] == -1 and pi['n_blocks'] == 256 and pi['pack_mode'] == 0, pi
     e.close()
 
 
@@ -170,14 +170,79 @@ def with_landmarks(p, degrees, seed=5):
 
 @pytest.mark.parametrize('fused', [True, False])
 def test_landmark_degree_64_and_65(oracle_mod, fused):
-    """63 / 64 fill one tile (whole landmark owned by the tile), 65 / 128 / 129 become chunk tiles whose landmark belief
-    comes from k_lmk_belief_list."""
+    """63 / 64 fill one tile (whole landmark owned by the tile), 65 / 128 / 129 become chunk tiles: each adds up its piece of the
+    landmark's messages (Params::parts) and k_lmk_finish_parts forms the belief."""
     base = make_synthetic(n_cams=140, n_lmks=60, obs_per_lmk=5, seed=31)
     prob = with_landmarks(base, [64, 65, 63, 128, 129, 2])
     gap, o, e = run_pair(oracle_mod, prob, fused=fused)
     assert gap < BELIEF_TOL, gap
     for a, b in zip(e.messages(), o.messages()):
         assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('obs,n_lmks,pack', [(40, 120, None), (100, 50, None), (23, 200, None), (10, 300, 'dense'), (3, 700, 'dense'), (7, 301, 'dense'),
+                                             (40, 120, 'whole')])
+def test_dense_packing_landmarks_span_tiles(oracle_mod, monkeypatch, fused, obs, n_lmks, pack):
+    """Dense packing (tile t = factors [64 t, 64 t + 64) of the landmark-major list; gbp_build.hpp): picked by the library when whole
+    landmarks would leave more than 15 % of the slots empty (40 or 23 factors per landmark: one or two per tile; 100: chunk tiles of
+    64 + 36), forced here on shapes it would not pick it for (GBP_PACK=dense: 10, 3, 7 factors per landmark -- parts of 1..9 factors at
+    every tile boundary, 21 landmarks in a tile) and forbidden on one it would (GBP_PACK=whole).  Same beliefs, messages and
+    relinearisation ages as the oracle either way, on the fused and on the general sweep."""
+    if pack:
+        monkeypatch.setenv('GBP_PACK', pack)
+    else:
+        monkeypatch.delenv('GBP_PACK', raising=False)
+    prob = make_synthetic(n_cams=130, n_lmks=n_lmks, obs_per_lmk=obs, seed=61)
+    gap, o, e = run_pair(oracle_mod, prob, fused=fused)
+    pi = e.plan_info()
+    want_dense = pack == 'dense' or (pack is None)
+    assert pi['pack_mode'] == (2 if want_dense else 0), pi
+    assert pi['n_tiles'] == ((prob.n_factors + 63) // 64 if want_dense else n_lmks * ((obs + 63) // 64)), pi
+    assert gap < BELIEF_TOL, gap
+    for a, b in zip(e.messages(), o.messages()):
+        assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+    # the other entry points that walk the layout: update_all_beliefs from the stored messages, the residual, the layout check
+    before = [a.copy() for a in e.beliefs()]
+    e.update_all_beliefs()
+    for a, b in zip(e.beliefs(), before):
+        assert rel_err_rows(a, b) < 1e-9
+    assert e.check_layout() == 0 and e.are() == pytest.approx(o.are(), rel=1e-6)
+
+
+def test_dense_packing_needs_three_factors_per_landmark(monkeypatch):
+    """One landmark of two factors: a 64-factor window could then touch more than 24 landmarks, so the dense packing is not offered
+    (not even on request) and the whole-landmark packing runs."""
+    from gbp_amd.engine import BAEngine
+    monkeypatch.setenv('GBP_PACK', 'dense')
+    prob = with_landmarks(make_synthetic(n_cams=130, n_lmks=100, obs_per_lmk=40, seed=7), [2])
+    e = BAEngine.from_problem(prob)
+    assert e.plan_info()['pack_mode'] == 0 and e.info()['n_tiles'] == 101
+    e.close()
+
+
+def test_tile_led_by_landmarks_without_factors(oracle_mod):
+    """Landmarks nobody observes take no slot but are owned by a tile (their belief is their prior).  Ten of them in front of landmarks
+    WITH factors: the tile's belief phase adds up seven landmarks per pass, and the sums of the first pass used to overwrite message
+    rows the second pass had not read yet (the assumption "landmark l's factors sit in lanes >= l" does not survive empty landmarks)."""
+    from gbp_amd.engine import BAEngine
+    base = make_synthetic(n_cams=12, n_lmks=9, obs_per_lmk=5, seed=77)
+    empty = 10
+    prob = BAProblem(K=base.K, cam_means=base.cam_means,
+                     lmk_means=np.concatenate([np.random.default_rng(1).uniform(-1, 1, (empty, 3)), base.lmk_means]), meas=base.meas,
+                     cam_idx=base.cam_idx, lmk_idx=(base.lmk_idx + empty).astype(np.int32))
+    for fused in (True, False):
+        e = BAEngine.from_problem(prob, fused=fused)
+        o = oracle_mod.OracleBA.from_problem(prob)
+        cov = [np.eye(6) * 1e-2] * prob.n_cams + [np.eye(3) * 1e-1] * prob.n_lmks     # (generate_priors_var gives an unobserved landmark a zero prior)
+        for g in (e, o):
+            g.set_priors_var(cov) if g is e else g.set_priors_var(cov[:prob.n_cams], cov[prob.n_cams:])
+            g.update_all_beliefs()
+            g.iterate(6)
+        assert e.info()['n_tiles'] == 1
+        gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs()))
+        assert gap < BELIEF_TOL, (fused, gap)
+        e.close()
 
 
 @pytest.mark.parametrize('n_lmks,n_tiles', [(24, 1), (25, 2), (48, 2), (49, 3)])
