@@ -82,6 +82,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack_next(const int *__restrict__ lpt
     while (e < L && nl < TILE_LMKS) {
         const int d = lptr[e + 1] - lptr[e];
         if (d > WTILE || nf + d > WTILE) break;
+        // The belief phase of a tile adds up seven landmarks per pass and writes the sums of pass b into scratch rows 7 b .. 7 b + 6
+        // while the messages of LATER passes still wait in their rows (tile_landmark_beliefs): the first factor of a landmark of pass
+        // b must sit in row 7 b or behind.  Landmarks without factors take no row, so a run of them could pull a later landmark's
+        // rows forward: such a landmark starts a new tile instead.  (Never the case when every landmark has a factor: nf >= nl.)
+        if (d > 0 && nf < 7 * (nl / 7)) break;
         nf += d; ++nl; ++e;
     }
     nxt[l] = e; w[l] = 1;

@@ -435,17 +435,17 @@ GBP_DEV void lmk_prefetch(const Params &p, int lane, int t, int l0, int nl, LmkP
 }
 
 // The landmark beliefs of a tile from the wave's LDS scratch wl = [64][9] new messages (eta 3 | Lambda 6 per factor lane): prior +
-// messages in adj_factors order (gbp.py:182-193), then mean and covariance.  The sums go back into the first rows of wl once every pass
-// has read its messages, and one lane per landmark solves and writes the record.  (One lane per landmark
+// messages in adj_factors order (gbp.py:182-193), then mean and covariance.  The sums go back into rows of wl that no later pass
+// reads -- the first factor of a landmark of pass b sits in row 7 b or behind: every landmark in front of it has a factor, or the
+// packer has made sure of it (landmarks without factors take no slot: gbp_build.hpp k_pack_next) -- and one lane per landmark
+// solves and writes the record.  (One lane per landmark
 // reading 9 doubles per message was the longest phase of the loop: 27 % of the wave-time with 6 of 64 lanes busy.)
 GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int t, int l0, int nl, const LmkPre &q)
 {
     const int g = (lane * 57) >> 9, k = lane - g * 9;
-    double sums[LMK_PASSES];
 #pragma unroll
     for (int b = 0; b < LMK_PASSES; ++b) {
-        sums[b] = 0.0;
-        if (b * 7 >= nl) continue;                          // wave-uniform
+        if (b * 7 >= nl) break;                             // wave-uniform
         const int li = b * 7 + g;
         const int rows = __shfl(q.rows, li, 64);
         if (g < 7 && li < nl) {
@@ -458,17 +458,8 @@ GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int t,
                 acc += v0; acc += v1; acc += v2; acc += v3;
             }
             for (; r < r1; ++r) acc += wl[r * 9 + k];
-            sums[b] = acc;
+            wl[li * 9 + k] = acc;
         }
-    }
-    // The sums go back into the scratch only when every pass has read its messages: landmark li's row may still hold the message of a
-    // LATER landmark's factor (landmarks without factors take no slot, so "landmark li's factors sit in lanes >= li" does not hold for
-    // the landmarks behind them; rounds 1-4 wrote inside the pass loop and a tile led by seven or more empty landmarks summed sums).
-    wave_lds_sync();
-#pragma unroll
-    for (int b = 0; b < LMK_PASSES; ++b) {
-        const int li = b * 7 + g;
-        if (b * 7 < nl && g < 7 && li < nl) wl[li * 9 + k] = sums[b];
     }
     wave_lds_sync();
     if (lane < nl) {

@@ -217,14 +217,16 @@ def test_dense_packing_needs_three_factors_per_landmark(monkeypatch):
     monkeypatch.setenv('GBP_PACK', 'dense')
     prob = with_landmarks(make_synthetic(n_cams=130, n_lmks=100, obs_per_lmk=40, seed=7), [2])
     e = BAEngine.from_problem(prob)
-    assert e.plan_info()['pack_mode'] == 0 and e.info()['n_tiles'] == 101
+    assert e.plan_info()['pack_mode'] == 0 and e.info()['n_tiles'] == 100      # (the two-factor landmark shares a tile with a 40-factor one)
     e.close()
 
 
 def test_tile_led_by_landmarks_without_factors(oracle_mod):
     """Landmarks nobody observes take no slot but are owned by a tile (their belief is their prior).  Ten of them in front of landmarks
-    WITH factors: the tile's belief phase adds up seven landmarks per pass, and the sums of the first pass used to overwrite message
-    rows the second pass had not read yet (the assumption "landmark l's factors sit in lanes >= l" does not survive empty landmarks)."""
+    WITH factors: the tile's belief phase adds up seven landmarks per pass and writes the sums of pass b into scratch rows 7 b .. 7 b + 6,
+    which must not hold messages a later pass has yet to read -- "landmark l's factors sit in rows >= l" does not survive empty
+    landmarks, so the packer starts a new tile where a run of them would pull a later landmark's rows forward (rounds 1-4 did not:
+    such a tile summed sums)."""
     from gbp_amd.engine import BAEngine
     base = make_synthetic(n_cams=12, n_lmks=9, obs_per_lmk=5, seed=77)
     empty = 10
@@ -239,7 +241,7 @@ def test_tile_led_by_landmarks_without_factors(oracle_mod):
             g.set_priors_var(cov) if g is e else g.set_priors_var(cov[:prob.n_cams], cov[prob.n_cams:])
             g.update_all_beliefs()
             g.iterate(6)
-        assert e.info()['n_tiles'] == 1
+        assert e.info()['n_tiles'] == 2                      # (the ten empty landmarks | the nine with factors: landmark 10 would have been landmark 10 of its tile -- pass 1 -- with its factors in rows 0-4)
         gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs()))
         assert gap < BELIEF_TOL, (fused, gap)
         e.close()
