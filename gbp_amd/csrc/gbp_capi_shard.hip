@@ -258,7 +258,7 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
     const bool big = with_messages && h->p.parts != nullptr;
     // Without a rendezvous hook everything behind the fused sweep is ONE launch (k_cam_reduce_xchg); logical ranks on one device
     // (the hook is set) keep reduce / push and finish apart, with the hook between them, so that they never spin on each other.
-    const bool merged = !h->xch_fn && with_messages && h->fused.enabled && !getenv("GBP_PEER_SPLIT");
+    const bool merged = !h->xch_fn && with_messages && !getenv("GBP_PEER_SPLIT");      // (fused: k_cam_reduce_xchg; general: k_cam_staged_xchg)
     bool finished = false;
     CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, &finished, big, &po, merged ? &w : nullptr));
     if (big) {

@@ -189,6 +189,29 @@ int gbp::sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_reli
             static const int forced = getenv("GBP_CAM_BLOCK") ? atoi(getenv("GBP_CAM_BLOCK")) : 0;
             // (and one wave per camera below 200 factors per camera: 1M factors x 20 000 cameras 176 against 243 us, 200k x 5 000 50.5 against 65.8)
             const int cam_block = forced ? forced : ((long long)h->p.F < 200LL * h->p.C ? 64 : (long long)h->p.F < 640LL * h->p.C ? 128 : BLOCK);
+            if (merged && peer) {
+                // peer-store exchange: sum -> push -> wait -> finish in this one launch; the grid must be resident at once (its workgroups
+                // wait for other ranks' workgroups), so never more workgroups than the occupancy query admits on this device
+                if (!h->staged_xchg_blocks[cam_block >> 7]) {
+                    int per_cu = 0;
+                    const void *fn = cam_block == 64 ? reinterpret_cast<const void *>(&k_cam_staged_xchg<64>)
+                                   : cam_block == 128 ? reinterpret_cast<const void *>(&k_cam_staged_xchg<128>) : reinterpret_cast<const void *>(&k_cam_staged_xchg<BLOCK>);
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, cam_block, 0));
+                    if (per_cu < 1 || h->n_cus < 1) return fail(GBP_EHIP, "occupancy query of the staged exchange kernel failed");
+                    int xb = per_cu * h->n_cus;
+                    if (const char *e = getenv("GBP_XCHG_BLOCKS")) xb = std::max(1, std::min(xb, atoi(e)));
+                    h->staged_xchg_blocks[cam_block >> 7] = xb;
+                }
+                const dim3 grid(std::min(h->p.C, h->staged_xchg_blocks[cam_block >> 7]));
+                PeerWait w = *merged;
+                w.clk = h->clk_cur ? h->clk_cur + 2 : nullptr;
+                if (cam_block == 64) hipLaunchKernelGGL(k_cam_staged_xchg<64>, grid, dim3(64), 0, h->stream, h->p, partial, *peer, w);
+                else if (cam_block == 128) hipLaunchKernelGGL(k_cam_staged_xchg<128>, grid, dim3(128), 0, h->stream, h->p, partial, *peer, w);
+                else hipLaunchKernelGGL(k_cam_staged_xchg<BLOCK>, grid, dim3(BLOCK), 0, h->stream, h->p, partial, *peer, w);
+                HIPCHK(hipGetLastError());
+                if (finished) *finished = true;
+                return GBP_OK;
+            }
             if (cam_block == 64) hipLaunchKernelGGL(k_cam_partial_staged<64>, dim3(h->p.C), dim3(64), 0, h->stream, h->p, partial, finish);
             else if (cam_block == 128) hipLaunchKernelGGL(k_cam_partial_staged<128>, dim3(h->p.C), dim3(128), 0, h->stream, h->p, partial, finish);
             else hipLaunchKernelGGL(k_cam_partial_staged<BLOCK>, dim3(h->p.C), dim3(BLOCK), 0, h->stream, h->p, partial, finish);

@@ -63,6 +63,7 @@ struct gbp_ba {
     bool has_beliefs = false;
     int n_cus = 0;
     bool staged_auto = false;                    // the general sweep was picked by the sparseness rule (build_graph), not asked for
+    int staged_xchg_blocks[3] = {0, 0, 0};       // grid cap of k_cam_staged_xchg<64 | 128 | 256> on this device (0: not asked yet)
     bool staged_attr_set = false;                // k_sweep_staged's dynamic-LDS attribute has been set on this handle's device (staged_launch)
     bool pending_possible = false;               // a stage-wise relinearise / compute_factors has run since the messages were last computed
     // dense message remainder allocated on demand (a damped factor that moves its linearisation point: enable_remainder)

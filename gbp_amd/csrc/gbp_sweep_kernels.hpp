@@ -124,12 +124,11 @@ __global__ __launch_bounds__(BLOCK, 1) void k_factor_tile(Params p)
 // (shuffle tree, then the four waves) -- bitwise reproducible.
 // finish != 0 (single GPU: nothing to exchange): the camera belief is completed here -- prior + sum, 6x6 solve (gbp.py:182-193) --
 // instead of in a dependent k_cam_finish launch.
+// the sum of camera c's messages from its staged rows: entry tid (< 27) in threads 0..26 (undefined elsewhere); red = [NT / 64][27] of LDS.
+// The caller synchronises the block before red is used again.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__restrict__ partial, int finish)
+GBP_DEV double cam_staged_sum(const Params &p, int c, double (*red)[27])
 {
-    __shared__ double red[NT / 64][27];
-    __shared__ double tot[27];
-    const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
@@ -169,10 +168,23 @@ __global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__r
         for (int k = 0; k < 27; ++k) red[wave][k] = acc[k];
     }
     __syncthreads();
+    double s2 = 0.0;
     if (threadIdx.x < 27) {
-        double s2 = red[0][threadIdx.x];
+        s2 = red[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) s2 += red[w][threadIdx.x];
+    }
+    return s2;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__restrict__ partial, int finish)
+{
+    __shared__ double red[NT / 64][27];
+    __shared__ double tot[27];
+    const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const double s2 = cam_staged_sum<NT>(p, c, red);
+    if (threadIdx.x < 27) {
         partial[(size_t)c * 27 + threadIdx.x] = s2;
         tot[threadIdx.x] = s2 + p.cprior[(size_t)c * 27 + threadIdx.x];
     }
@@ -188,6 +200,30 @@ __global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__r
     }
 }
 
+// The general sweep under the peer-store exchange, everything after the factor kernel in ONE launch (the staged counterpart of
+// k_cam_reduce_xchg, gbp_fused.hpp): a grid of persistent workgroups, never larger than what is resident at once, first sums and
+// PUSHES all of its cameras (staged rows -> 27 sums -> row c of every rank's mailbox + tag), then finishes them, one wave per camera
+// (wait for the n_ranks tags of row c, add the parts in rank order, prior, mean | covariance).  Same sums, bitwise, as
+// k_cam_partial_staged + k_peer_push + k_cam_finish, which remain the path of logical ranks that share one device (rendezvous hook).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_cam_staged_xchg(Params p, double *__restrict__ partial, PeerOut peer, PeerWait wait)
+{
+    __shared__ double red[NT / 64][27];
+    const int tid = threadIdx.x;
+    if (wait.clk && blockIdx.x == 0 && tid == 0) *wait.clk = (unsigned long long)wall_clock64();
+    for (int b = blockIdx.x; b < p.C; b += gridDim.x) {
+        const int c = p.reverse_walk ? p.C - 1 - b : b;
+        const double s = cam_staged_sum<NT>(p, c, red);
+        if (tid < 64) {
+            if (tid < 27) partial[(size_t)c * 27 + tid] = s;
+            peer_push_row(peer, c, s, tid);
+        }
+        __syncthreads();                                     // red is overwritten by the next camera
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int b = blockIdx.x + wave * gridDim.x; b < p.C; b += (NT / 64) * gridDim.x)
+        cam_finish_wave(p, nullptr, peer.n, 0, wait, p.reverse_walk ? p.C - 1 - b : b, lane);
+}
 
 __global__ __launch_bounds__(BLOCK) void k_lmk_belief(Params p)
 {

@@ -40,7 +40,8 @@ def main():
         e.close()
         dist.destroy_process_group()
         return
-    g = ShardedBA(p, device=0, exchange='peer')
+    fused = {'0': False, '1': True}.get(os.environ.get('GBP_TEST_FUSED', ''), None)      # (None: the library picks the sweep)
+    g = ShardedBA(p, device=0, exchange='peer', fused=fused)
     assert g.library_loop and g.exchange == 'peer', (g.library_loop, g.exchange)
     g.generate_priors_var(50.0)
     g.update_all_beliefs()

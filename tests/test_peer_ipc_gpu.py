@@ -79,6 +79,31 @@ def test_peer_exchange_between_processes(tmp_path, world, n_cams, n_lmks):
     assert lo == p.n_lmks
 
 
+@pytest.mark.parametrize('world,n_cams,n_lmks', [(2, 60, 4000), (3, 700, 9000)])
+def test_peer_exchange_general_sweep_between_processes(tmp_path, world, n_cams, n_lmks):
+    """The general sweep under the peer-store exchange: everything behind the factor kernel is ONE launch (k_cam_staged_xchg: staged rows ->
+    camera sums -> mailboxes of all ranks -> wait -> rank-ordered finish), between real processes; 700 cameras do not fit the fused
+    sweep's table at all.  Against one engine on the whole graph."""
+    from gbp_amd.engine import BAEngine
+    n_sweeps = 12
+    p = make_synthetic(n_cams=n_cams, n_lmks=n_lmks, obs_per_lmk=10, seed=2)
+    ref = BAEngine.from_problem(p, fused=False)
+    ref.generate_priors_var(50.0)
+    ref.update_all_beliefs()
+    ref.iterate(n_sweeps)
+    rce, rcl, rle, rll = ref.beliefs()
+    are = ref.are()
+    ref.close()
+    ranks = run_ranks(tmp_path, world, n_sweeps, n_cams, n_lmks, extra_env={'GBP_TEST_FUSED': '0'})
+    for r in ranks:
+        assert str(r['kind']) == 'peer' and int(r['n_ranks']) == world
+        assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])
+        assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
+        a, b = int(r['lo']), int(r['hi'])
+        assert rel_err_rows(r['le'], rle[a:b]) < 1e-6 and rel_err_rows(r['ll'], rll[a:b]) < 1e-6
+        assert float(r['are']) == pytest.approx(are, rel=1e-8)
+
+
 def test_peer_exchange_split_launches_between_processes(tmp_path):
     """GBP_PEER_SPLIT=1: reduce / push and the waiting finish as two launches (what the general sweep and update_all_beliefs always
     use), also across processes."""

@@ -21,8 +21,8 @@ rows = []
 for n_l in args.sizes:
     p = make_synthetic(n_cams=500, n_lmks=n_l, obs_per_lmk=10, seed=0)
     for mode in args.modes:
-        e = BAEngine.from_problem(p, fused=(mode != 'general'))
-        if mode == 'peer1':
+        e = BAEngine.from_problem(p, fused=(mode not in ('general', 'peer1g')))
+        if mode in ('peer1', 'peer1g'):              # peer1g: the general sweep under the exchange (k_sweep_staged + k_cam_staged_xchg)
             e.peer_connect(0, [e.peer_export(1)])
             it, upd = e.iterate_sharded, e.update_beliefs_sharded
         else:
