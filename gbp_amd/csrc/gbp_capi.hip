@@ -237,8 +237,10 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         // Few factors per camera: the fused sweep writes (and its reduce reads back) one 224-byte table row per camera and WORKGROUP
         // whatever the graph's size, the staged form one 128-byte row per FACTOR.  Below ~0.75 factors per (workgroup, camera) the
         // staged sweep is the faster one -- 13k / 30k / 60k / 90k factors x 500 cameras: 18.6 / 20.5 / 24.2 / 29.1 against 26.3 /
-        // 28.6 / 28.9 / 30.2 us per sweep, 125k: 35.8 against 32.8 (profiles/r04_shards.json) -- e.g. a rank's share at 16 ranks and
-        // beyond.  GBP_STAGED_BELOW overrides the 0.75 (0: never).
+        // 28.6 / 28.9 / 30.2 us per sweep (profiles/r04_shards.json); round 5: 62.5k 22.1 against 28.6; 125k is a tie (30.6 against 31.4,
+        // with the peer-store exchange in the loop 34.5 against 35.3), 250k 44.6 against 36.9 (profiles/r05_shards.json) -- e.g. a rank's
+        // share of the headline graph at 16 ranks and beyond.  Not a byte count: fr1desk (13 298 factors, 63 cameras, 221 workgroups: 0.96
+        // per pair) runs 13.9 us fused against ~16 staged, so the threshold stays below 1.  GBP_STAGED_BELOW overrides it (0: never).
         double staged_below = 0.75;
         if (const char *e = getenv("GBP_STAGED_BELOW")) staged_below = atof(e);
         const bool sparse = (double)F < staged_below * (double)n_wg * (double)C;

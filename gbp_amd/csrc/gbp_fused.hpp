@@ -429,10 +429,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     const int c = blockIdx.x, tid = threadIdx.x;
     clk_begin(clk);
     double *tot = sh + (RED_PARTS + RED_G) * TROW;
+    const double pri = tid < 27 ? p.cprior[(size_t)c * 27 + tid] : 0.0;      // (asked for ahead of the tables: one round trip less in the tail)
     const double s = cam_reduce_sum<RED_THREADS>(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);
     if (tid < 27) {
         partial[(size_t)c * 27 + tid] = s;
-        tot[tid] = s + p.cprior[(size_t)c * 27 + tid];
+        tot[tid] = s + pri;
     }
     if (peer.n && tid < 64) peer_push_row(peer, c, s, tid);   // sharded, peer-store exchange: straight into every rank's mailbox
     if (!finish) return;

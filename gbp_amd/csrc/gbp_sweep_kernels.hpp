@@ -183,10 +183,11 @@ __global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__r
     __shared__ double red[NT / 64][27];
     __shared__ double tot[27];
     const int c = p.reverse_walk ? p.C - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const double pri = threadIdx.x < 27 ? p.cprior[(size_t)c * 27 + threadIdx.x] : 0.0;      // (asked for ahead of the rows: one round trip less in the tail)
     const double s2 = cam_staged_sum<NT>(p, c, red);
     if (threadIdx.x < 27) {
         partial[(size_t)c * 27 + threadIdx.x] = s2;
-        tot[threadIdx.x] = s2 + p.cprior[(size_t)c * 27 + threadIdx.x];
+        tot[threadIdx.x] = s2 + pri;
     }
     if (!finish) return;
     __syncthreads();
