@@ -42,6 +42,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
+COPY_CEILING_GBS = 6290.0      # measured float4 copy on MI355X, same line of the guide: what a pure streaming kernel reaches
 MIN_TIMED_S = 0.5
 STAMPS = 1 << 30              # gbp_ba_set_kernel_timing(STAMPS): device-clock stamps in every launch, HIP events around the first one only
 EVENT_EVERY = 7               # HIP events bracket every 7th launch of the dominant kernel in the instrumented replay (cross-check)
@@ -535,21 +536,35 @@ def main(shard_factory=None, script=None):
         g = BAEngine.from_problem(big, device=local_rank)
         try:
             g.generate_priors_var(50.0); g.update_all_beliefs(); g.sync(); g.snapshot_state()
-            best = None
+            best = best_steady = None
+            n_steady = 0
             for rep in range(3):
                 g.set_kernel_timing(STAMPS)                        # (before the warm-up, as in batch())
                 g.iterate(160)                                     # (clocks up: see batch())
                 g.restore_snapshot(); g.iterate(5); g.sync()
                 g.iterate(20); g.sync()
                 clk = g.sweep_clocks()[165:185]
+                relin = np.asarray(g.relin_counts(20), dtype=np.int64)
                 g.set_kernel_timing(0)
-                k = float(np.nanmean((clk[:, 2] - clk[:, 0]) * 1e-3))
+                sw = (clk[:, 2] - clk[:, 0]) * 1e-3
+                k = float(np.nanmean(sw))
                 best = k if best is None else min(best, k)
+                steady = (relin * 1000 < big.n_factors) & np.isfinite(sw)          # the sweeps SURVEY 8d's byte count describes: nobody relinearises
+                if steady.any():
+                    ks = float(sw[steady].mean())
+                    best_steady = ks if best_steady is None else min(best_steady, ks)
+                    n_steady = int(steady.sum())
             lay = layout_bytes(big.n_factors, big.n_lmks, big.n_cams, g.info()['n_blocks'], True)
-            return {"n_factors": int(big.n_factors), "n_lmks": int(big.n_lmks), "kernel_avg_ms": best, "bytes_per_launch": lay,
-                    "achieved": lay / (best * 1e-3) / 1e9, "frac": lay / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "same kernel, sweeps 6-25 of the batch schedule (two of them relinearise every factor), best of three replays; "
-                            "state >> the 256 MiB memory-side cache"}
+            out = {"n_factors": int(big.n_factors), "n_lmks": int(big.n_lmks), "kernel_avg_ms": best, "bytes_per_launch": lay,
+                   "achieved": lay / (best * 1e-3) / 1e9, "frac": lay / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "frac_of_copy_ceiling": lay / (best * 1e-3) / 1e9 / COPY_CEILING_GBS,
+                   "note": "same kernel, sweeps 6-25 of the batch schedule (two of them relinearise every factor and move 72 B per factor more than "
+                           "bytes_per_launch counts), best of three replays; state >> the 256 MiB memory-side cache"}
+            if best_steady:
+                out.update({"kernel_steady_ms": best_steady, "kernel_steady_launches": n_steady,
+                            "frac_steady": lay / (best_steady * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "frac_steady_of_copy_ceiling": lay / (best_steady * 1e-3) / 1e9 / COPY_CEILING_GBS})
+            return out
         finally:
             g.close()
 
@@ -591,6 +606,7 @@ def main(shard_factory=None, script=None):
         traffic, traffic_src = measured_traffic() if (world == 1 and fused and F == 1_000_000 and not dry) else (None, None)
         lib_hash = None if dry else library_fingerprint()
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_copy_ceiling": achieved / COPY_CEILING_GBS, "copy_ceiling": COPY_CEILING_GBS,
                 "traffic": traffic, "kernel": m['k_name'], "bytes_per_launch": lay,
                 "bytes_model": "engine layout, DESIGN.md section 4: F*(31 doubles + 8 B) + L*29 doubles + camera tables",
                 "library_sha256_16": lib_hash,
@@ -668,7 +684,8 @@ def main(shard_factory=None, script=None):
         if pc is not None:
             out["parity_check"] = pc
         if hbm is not None:
-            roof["frac_hbm_bound"] = hbm["frac"]
+            roof["frac_hbm_bound"] = hbm["frac"]                 # the HONEST fraction of the HBM peak: `frac` above is cache-assisted (the 1M
+            roof["frac_hbm_bound_of_copy_ceiling"] = hbm["frac_of_copy_ceiling"]      # graph's working set sits in the 256 MiB memory-side cache)
             roof["hbm_bound_size"] = hbm
         return out
 
