@@ -395,7 +395,23 @@ def g14(ref, which=('vsmall', 'small', 'vsmall_huber')):
              are=np.array(are), energy=np.array(energy), n_relin=np.array(relins, dtype=np.int32), **out)
 
 
-ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14)
+def g15(ref):
+    """ba.py --float_implementation through its relinearisation waves: the priors start 50 x weaker than the factors and are weakened
+    five more times (x 0.4 in information before sweeps 2, 4, 6, 8, 10; ba.py:86-88, gbp_ba.py:36-42) until they are 500 x weaker in standard
+    deviation -- beliefs
+    of landmarks with two observations are then held by almost nothing but two rank-2 messages -- and the run goes on to sweep 40,
+    through the waves of sweeps 16, 25 and 34 in which every factor relinearises.  (G7 stops at sweep 12, before the first wave.)
+    Beliefs after sweeps 12, 17, 26, 35, 40; ARE / energy / relinearisation counts every sweep."""
+    from gbp import gbp_ba
+    for tag, fname in (('vsmall', 'fr1desk_vsmall.txt'), ('small', 'fr1desk_small.txt')):
+        graph, out = replay(gbp_ba, os.path.join(HERE, 'data', fname), 40, checkpoints=(12, 17, 26, 35, 40), float_impl=True)
+        out['cam_prior_lambda'] = np.array([n.prior.lam[0, 0] for n in graph.cam_nodes])
+        out['lmk_prior_lambda'] = np.array([n.prior.lam[0, 0] for n in graph.lmk_nodes])
+        out['lmk_degree'] = np.array([len(n.adj_factors) for n in graph.lmk_nodes], dtype=np.int32)
+        save(f'G15_floatimpl_40it_{tag}', bal=np.array(fname), **out)
+
+
+ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14, G15=g15)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
