@@ -10,11 +10,11 @@ to the GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
-import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,19 +54,24 @@ def build(force=False, out=None, defines=(), extra_flags=(), capture=False):
     hipcc = hipcc_path()
     flags = FLAGS + [f'-D{d}' for d in defines] + list(extra_flags)
     log = []
-    with tempfile.TemporaryDirectory(prefix='gbp_build_') as tmp:
-        def compile_one(src):
-            obj = os.path.join(tmp, os.path.splitext(src)[0] + '.o')
-            r = subprocess.run([hipcc] + flags + ['-c', src, '-o', obj], cwd=CSRC, capture_output=True, text=True)
-            if r.returncode != 0:
-                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
-            log.append(r.stderr)
-            return obj
-        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
-            objs = list(pool.map(compile_one, SOURCES))
-        r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs, cwd=CSRC, capture_output=True, text=True)
+    # a FIXED object directory (git-ignored `build/`): object paths end up inside the library, and the library's sha256 must be the same
+    # wherever and whenever these sources are built (bench.py ties committed counter passes to it)
+    tmp = os.path.join(HERE, 'build', 'obj_' + hashlib.sha256(' '.join(flags).encode()).hexdigest()[:12])
+    os.makedirs(tmp, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(tmp, os.path.splitext(src)[0] + '.o')
+        r = subprocess.run([hipcc] + flags + ['-c', src, '-o', os.path.relpath(obj, CSRC)], cwd=CSRC, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"linking {lib} failed:\n{r.stderr[-6000:]}")
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+        log.append(r.stderr)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + [os.path.relpath(o, CSRC) for o in objs], cwd=CSRC,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"linking {lib} failed:\n{r.stderr[-6000:]}")
     return (lib, ''.join(log)) if capture else lib
 
 
