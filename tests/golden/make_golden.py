@@ -365,7 +365,8 @@ def g14(ref, which=('vsmall', 'small', 'vsmall_huber')):
     those checkpoints (where two trajectories part, this is the first thing to differ).  One file per run: they take 90-200 s of
     reference time each and can be made in parallel (`--only G14:small`)."""
     from gbp import gbp_ba
-    runs = dict(vsmall=('fr1desk_vsmall.txt', {}), small=('fr1desk_small.txt', {}), vsmall_huber=('fr1desk_vsmall.txt', dict(loss='huber')))
+    runs = dict(vsmall=('fr1desk_vsmall.txt', {}), small=('fr1desk_small.txt', {}), vsmall_huber=('fr1desk_vsmall.txt', dict(loss='huber')),
+                desk=('fr1desk.txt', {}))                    # (desk: BASELINE config 3 at full length, ~10 min of reference time: `--only G14:desk`)
     for tag in which:
         fname, over = runs[tag]
         cfg = default_configs(**over)

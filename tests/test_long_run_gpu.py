@@ -21,7 +21,7 @@ BELIEF_TOL = 1e-6           # (observed: ~1e-8; BASELINE north_star asks for 1e-
 
 
 @pytest.mark.parametrize('fused', [True, False, None], ids=['fused', 'general', 'auto'])
-@pytest.mark.parametrize('tag,loss', [('vsmall', None), ('small', None), ('vsmall_huber', 'huber')])
+@pytest.mark.parametrize('tag,loss', [('vsmall', None), ('small', None), ('vsmall_huber', 'huber'), ('desk', None)])
 def test_g14_ba_default_length(oracle_mod, tag, loss, fused):
     from gbp_amd.engine import BAEngine
     g = golden(f'G14_200it_{tag}')

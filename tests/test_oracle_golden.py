@@ -333,7 +333,7 @@ def test_g13_damped_relinearisation_against_the_reference(oracle_mod):
     g13_sequence(graph, g, oracle_mod.replay_ba, lambda o, tag: g13_check(g, o, tag, 1e-7, 1e-6))
 
 
-@pytest.mark.parametrize('tag,loss', [('vsmall', None), ('small', None), ('vsmall_huber', 'huber')])
+@pytest.mark.parametrize('tag,loss', [('vsmall', None), ('small', None), ('vsmall_huber', 'huber'), ('desk', None)])
 def test_g14_ba_default_length(oracle_mod, tag, loss):
     """The reference's own run length (ba.py:13: 200 sweeps; fixture G14): the oracle relinearises the same factors in the same sweep
     as the reference all the way -- from sweep ~60 on some factors relinearise in every sweep -- and its beliefs stay within 1e-6
