@@ -410,9 +410,14 @@ def main(shard_factory=None, script=None):
             if timing and not dry:
                 # The host work around an instrumented replay (switching the stamps on, reading them back, numpy) leaves the GPU idle
                 # for milliseconds; it drops its clocks, and a 20-sweep batch is over before they are back: such replays measured
-                # sweeps 4-9 % longer than the timed batches they stand for.  About 25 ms of throw-away sweeps (the state is restored
-                # right after) put the clocks where the back-to-back timed batches find them.
-                graph.iterate(spin[0])
+                # sweeps 4-9 % longer than the timed batches they stand for.  About 25 ms of throw-away sweeps put the clocks where the
+                # back-to-back timed batches find them.  They are whole replays of the batch (restore, W + K sweeps), so that every launch
+                # of the process is one of the schedule's sweeps and rocprofv3's average over ALL launches of this command is an average
+                # of the same sweeps `value` times (sweeps that simply ran on from wherever the state was sat deep in the regime where
+                # factors relinearise every sweep, and pulled that average 6 % above the timed one).
+                for _ in range(spin[0] // (args.warmup + args.steps)):
+                    graph.restore_snapshot()
+                    graph.iterate(args.warmup + args.steps)
             if not dry:
                 graph.restore_snapshot()
             graph.iterate(args.warmup)
@@ -444,7 +449,8 @@ def main(shard_factory=None, script=None):
             # (A single replay can land on a slow patch -- one in a few is 5 % off the median batch -- so the replay is repeated and the
             #  one whose device step is closest to the median batch time is the one reported: the picture of a TYPICAL batch.)
             want_us = float(np.median(times)) / args.steps * 1e6
-            spin[0] = int(min(max(40, 25e3 / want_us), max(0, CLK_RING - args.warmup - args.steps)))
+            per = args.warmup + args.steps                     # (whole batches, and what the stamp ring holds besides the measured one)
+            spin[0] = per * int(min(max(1, -(-25e3 // (want_us * per))), max(0, (CLK_RING - per) // per)))
             for rep in range(3):
                 batch(timing=STAMPS)                           # stamps only (events around the first launch alone)
                 clk = graph.sweep_clocks()[spin[0] + args.warmup:spin[0] + args.warmup + args.steps]      # (the throw-away and warm-up sweeps are stamped too)
@@ -540,10 +546,11 @@ def main(shard_factory=None, script=None):
             n_steady = 0
             for rep in range(3):
                 g.set_kernel_timing(STAMPS)                        # (before the warm-up, as in batch())
-                g.iterate(160)                                     # (clocks up: see batch())
+                for _ in range(6):                                 # (clocks up with whole replays of the batch: see batch())
+                    g.restore_snapshot(); g.iterate(25)
                 g.restore_snapshot(); g.iterate(5); g.sync()
                 g.iterate(20); g.sync()
-                clk = g.sweep_clocks()[165:185]
+                clk = g.sweep_clocks()[155:175]
                 relin = np.asarray(g.relin_counts(20), dtype=np.int64)
                 g.set_kernel_timing(0)
                 sw = (clk[:, 2] - clk[:, 0]) * 1e-3
