@@ -321,3 +321,30 @@ def test_peer_exchange_times_out_instead_of_hanging(monkeypatch):
     assert ei.value.code == -5 and 'timed out' in str(ei.value)
     a.sync()                                                  # the error is reported once
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('obs', [40, 100])
+def test_sharded_with_landmarks_that_span_tiles(oracle_mod, fused, obs):
+    """Shards whose landmarks span tiles (dense packing at 40 factors per landmark, 100: more than a tile): the beliefs of those landmarks
+    are formed by k_lmk_finish_parts on a side stream BESIDE the camera exchange, and the next sweep must wait for them.  Two ranks,
+    in-library loop, against one engine on the whole graph."""
+    from gbp_amd.engine import BAEngine
+    p = make_synthetic(n_cams=130, n_lmks=80 if obs == 40 else 36, obs_per_lmk=obs, seed=23)
+    ref = BAEngine.from_problem(p, fused=fused)
+    assert ref.plan_info()['pack_mode'] == 2
+    ref.generate_priors_var(50.0)
+    ref.update_all_beliefs()
+    ares, energies = oracle_mod.replay_ba(ref, 14, diagnostics=True)
+    rce, rcl, rle, rll = ref.beliefs()
+    ranks = run_world(p, 2, fused, 14, oracle_mod, True)
+    lo = 0
+    for r in ranks:
+        assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])
+        assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
+        a, b = r['rng']
+        assert a == lo
+        lo = b
+        assert rel_err_rows(r['le'], rle[a:b]) < 1e-6 and rel_err_rows(r['ll'], rll[a:b]) < 1e-6
+        assert np.allclose(r['ares'], ares, rtol=1e-7)
+    assert lo == p.n_lmks
