@@ -13,9 +13,10 @@ from conftest import REPO
 
 
 @pytest.mark.timeout(600)
-def test_bench_spawns_its_own_ranks(oracle_mod):
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_spawns_its_own_ranks(oracle_mod, world):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    cmd = [sys.executable, os.path.join(REPO, 'tests', 'tools', 'bench_dry_launch.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+    cmd = [sys.executable, os.path.join(REPO, 'tests', 'tools', 'bench_dry_launch.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1',
            '--bal', os.path.join(REPO, 'tests', 'golden', 'data', 'fr1desk_vsmall.txt'),
            '--backend', 'gloo', '--single-batch']
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
@@ -23,7 +24,7 @@ def test_bench_spawns_its_own_ranks(oracle_mod):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['dry_run'] is True
+    assert out['n_gpus'] == world and out['steps'] == 3 and out['dry_run'] is True
     assert out['value'] > 0 and out['scaling'] == 'strong' and out['config']['n_factors'] == 1801
     assert 0.0 <= out['roofline']['frac'] <= 1.0
 
