@@ -159,9 +159,9 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     HIPCHK(hipGetLastError());
 
     clk.mark("orders (allocs + 2 sorts)");
-    // 4. tiles: up to 64 slots / TILE_LMKS whole landmarks each; over-sized landmarks become chunk tiles (nl = 0).
-    //    Next-fit packing as list ranking on the device (gbp_build.hpp); only the tile count and the (few) over-sized landmarks
-    //    come back.
+    // 4. tiles: up to 64 slots / TILE_LMKS whole landmarks each; over-sized landmarks become chunk tiles (a piece of one landmark
+    //    each).  Next-fit packing as list ranking on the device (gbp_build.hpp); only the tile count, the number of over-sized
+    //    landmarks and the smallest landmark degree come back -- the last one decides whether the dense packing may replace this one.
     const int LP = L + 1;
     const int n_pblocks = std::max(1, (L + PACK_BLOCK - 1) / PACK_BLOCK), n_nodes = n_pblocks * TILE_LMKS + 1;   // (block, entry) nodes + the end
     int levels = 1;
