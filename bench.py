@@ -55,13 +55,13 @@ def survey_bytes(F, L, C):
     return F * 1072 + L * 168 + C * 480
 
 
-def layout_bytes(F, L, C, n_blocks, fused):
+def layout_bytes(F, L, C, n_blocks, fused, table_rows=None):
     """Bytes one launch of the dominant kernel must move in THIS engine's layout."""
     per_factor = (21 + 10) * 8 + 8        # x0 9 z 2 | messages 10 in, 10 out | meta 4 B + state 4 B in (a factor that only ages writes no state:
                                           # the word holds the clock value of its last relinearisation; PMC write traffic 138 -> 119 MB)
     per_lmk = 20 * 8 + 9 * 8              # record (mean 3 | covariance 6 | rows | prior 9 | pad) in, mean | covariance out
-    if fused:                             # k_sweep_wat: + one table row (27 sums + 1 pad double) per camera and workgroup out
-        return F * per_factor + L * per_lmk + n_blocks * C * 28 * 8
+    if fused:                             # k_sweep_wat: + one table row (27 sums + 1 pad double) per camera and workgroup out (camera windows:
+        return F * per_factor + L * per_lmk + (table_rows if table_rows else n_blocks * C) * 28 * 8      # per camera of the workgroup's window)
     # k_factor_tile: the same per-factor / per-landmark streams + what rebuilds the camera message, staged camera-major
     # (x0 9 | q_C 2 | W 3 in one whole 128-byte line, + cpos)
     return F * (per_factor + 16 * 8 + 4) + L * per_lmk
@@ -234,13 +234,13 @@ def try_peer_exchange(args, problem, local_rank, dist, torch, measure, rccl_grap
 G9B = os.path.join(REPO, 'tests', 'golden', 'G9b_synthetic_full_1000000.npz')
 
 
-def parity_check(graph, problem, dist, torch, side_dev, world, local_rank, n_sweeps=10):
+def parity_check(graph, problem, dist, torch, side_dev, world, local_rank, n_sweeps=10, default_graph=True):
     """Outside the timed region, every rank: the first ten sweeps of the batch schedule once more, against fixture G9b -- the
     REFERENCE's own run of this very graph (tests/golden/make_g9b.py: 500 camera beliefs after sweep 10, the ARE after every sweep).
     Makes a multi-GPU line self-proving: (i) camera beliefs bitwise equal on all ranks, (ii) < 1e-6 from the reference's at sweep 10,
     (iii) the ARE trace, (iv) how many ranks the exchange itself reports and how many distinct devices they sit on."""
     out = {"fixture": None, "ok": None}
-    is_headline = (problem.n_factors == 1_000_000 and problem.n_cams == 500 and problem.n_lmks == 100_000 and os.path.exists(G9B))
+    is_headline = (default_graph and problem.n_factors == 1_000_000 and problem.n_cams == 500 and problem.n_lmks == 100_000 and os.path.exists(G9B))
     g = np.load(G9B) if is_headline else None
     graph.restore_snapshot()
     ares = [graph.are()]
@@ -317,6 +317,8 @@ def main(shard_factory=None, script=None):
     ap.add_argument('--cams', type=int, default=500)
     ap.add_argument('--lmks', type=int, default=100_000)
     ap.add_argument('--obs', type=int, default=10)
+    ap.add_argument('--window', type=int, default=None, help='a SEQUENCE instead of the headline graph: every landmark is seen from --obs of this many '
+                    'consecutive cameras (make_synthetic(window=...)); the fused sweep then runs with per-workgroup camera windows')
     ap.add_argument('--bal', default=None, help='BAL text file instead of the synthetic graph (BASELINE configs 2-3, e.g. '
                                                 'tests/golden/data/fr1desk.txt); not the headline workload')
     ap.add_argument('--no-fused', action='store_true')
@@ -363,8 +365,8 @@ def main(shard_factory=None, script=None):
         workload = f"BAL file {os.path.basename(args.bal)}"
     else:
         from gbp_amd.synthetic import make_synthetic
-        problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0)
-        workload = "synthetic BAL"
+        problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0, window=args.window)
+        workload = "synthetic BAL" if args.window is None else f"synthetic sequence (window {args.window})"
     F, L, C = problem.n_factors, problem.n_lmks, problem.n_cams
 
     # one node: the collectives' bootstrap sockets need no NIC and no resolvable hostname (the data path is xGMI either way)
@@ -514,7 +516,8 @@ def main(shard_factory=None, script=None):
             return None
         info = g.info()
         fused = bool(info.get('fused'))
-        lay = layout_bytes(g.F, g.L, C, info.get('n_blocks', 0), fused)
+        pl = getattr(g, 'engine', g).plan_info()
+        lay = layout_bytes(g.F, g.L, C, info.get('n_blocks', 0), fused, pl.get('table_rows') if pl.get('max_window') else None)
         mine = [mean_ms(pic[k], pic['ok']) or 0.0 for k in ('sweep', 'reduce', 'finish')] + [mean_ms(pic['step'], pic['ok'][:-1]) or 0.0,
                 float(g.F), float(g.comm_info()['n_ranks']), float(g.L), float(lay), 1.0 if fused else 0.0,
                 mean_ms(pic['sweep'], np.isfinite(pic['sweep'])) or 0.0]
@@ -538,7 +541,7 @@ def main(shard_factory=None, script=None):
         travel together in one line."""
         from gbp_amd.engine import BAEngine
         from gbp_amd.synthetic import make_synthetic
-        big = make_synthetic(n_cams=args.cams, n_lmks=2 * args.lmks, obs_per_lmk=args.obs, seed=0)
+        big = make_synthetic(n_cams=args.cams, n_lmks=2 * args.lmks, obs_per_lmk=args.obs, seed=0, window=args.window)
         g = BAEngine.from_problem(big, device=local_rank)
         try:
             g.generate_priors_var(50.0); g.update_all_beliefs(); g.sync(); g.snapshot_state()
@@ -585,7 +588,8 @@ def main(shard_factory=None, script=None):
         its = args.steps / dt_med
         F_local, L_local = graph.F, graph.L
         fused = bool(info.get('fused'))
-        lay = layout_bytes(F_local, L_local, C, info.get('n_blocks', 0), fused)
+        plan = {} if dry else getattr(graph, 'engine', graph).plan_info()
+        lay = layout_bytes(F_local, L_local, C, info.get('n_blocks', 0), fused, plan.get('table_rows') if plan.get('max_window') else None)
         ms_step = dt_med / args.steps * 1e3
         k_steady = k_med = k_min = 0.0
         n_steady = 0
@@ -623,7 +627,7 @@ def main(shard_factory=None, script=None):
                 "survey_equivalent_bytes": survey_bytes(F_local, L_local, C),
                 "survey_equivalent_gbs": survey_bytes(F_local, L_local, C) / (k_steady * 1e-3) / 1e9 if k_steady else 0.0}
         if red_ms is not None:
-            roof["reduce_kernel"] = "k_cam_reduce_tree"
+            roof["reduce_kernel"] = "k_cam_reduce_rows" if plan.get('max_window') else "k_cam_reduce_tree"      # (windows with more than 64 rows on one camera keep the tree form)
             roof["reduce_avg_ms"] = red_ms
             roof["step_ms_device"] = mean_ms(pic['step'])
             # a kernel cannot take longer than the step that contains it
@@ -668,6 +672,7 @@ def main(shard_factory=None, script=None):
                        "exchange_requested": args.exchange if (world > 1 or args.sharded) else None,
                        "exchange_fallback": getattr(graph, 'exchange_fallback', None),
                        "sweep": "fused" if fused else "general",
+                       "camera_windows": {"widest": plan['max_window'], "table_rows": plan['table_rows']} if plan.get('max_window') else None,
                        "loop": ("python" if (args.python_loop or dry) else "in-library") if (world > 1 or args.sharded) else "gbp_ba_iterate"},
             "timing": {"protocol": "state restored before every batch; W warm-up + K timed sweeps between barrier+synchronize; median over batches",
                        "batches": int(times.size), "timed_seconds": float(times.sum()),
@@ -699,7 +704,7 @@ def main(shard_factory=None, script=None):
     m = measure(graph)
     exchange_used = getattr(graph, 'exchange', None)
     # outside the timed region: the first ten sweeps once more, against the reference's own run of this graph (fixture G9b)
-    pc = None if dry else parity_check(graph, problem, dist, torch, side_dev, world, local_rank)
+    pc = None if dry else parity_check(graph, problem, dist, torch, side_dev, world, local_rank, default_graph=args.window is None and not args.bal)
     per_rank = gather_per_rank(m)
     alt = None
     peer_unavailable = None

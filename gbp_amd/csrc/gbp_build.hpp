@@ -271,6 +271,31 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
     p.lin[lin_at(slot, ROW_Z + 1)] = a.meas[(size_t)fi * 2 + 1];
 }
 
+// out[b] = {lowest, highest} camera among the factors of the tiles that workgroup b of the fused sweep walks (tiles [b T / n, (b + 1) T / n),
+// k_sweep_wat): the workgroup's camera WINDOW (fused_plan).  One wave per workgroup, the slot -> factor decode of k_build_tiles.
+__global__ __launch_bounds__(BLOCK) void k_wg_cam_range(const int4 *__restrict__ tiles, const int *__restrict__ lrow0, const int *__restrict__ lptr,
+                                                        const int *__restrict__ lm2ref, const int *__restrict__ ref_cam, int T, int n_wg,
+                                                        int2 *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, b = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (b >= n_wg) return;
+    const int t0 = (int)((long long)b * T / n_wg), t1 = (int)((long long)(b + 1) * T / n_wg);
+    int lo = 0x7fffffff, hi = -1;
+    for (int t = t0; t < t1; ++t) {
+        const int4 td = tiles[t];
+        const int slot = t * WTILE + lane;
+        if (lane < td.z) {
+            int k = 0;
+            for (int i = 1; i < td.y; ++i) k += (lrow0[td.x + i] <= slot) ? 1 : 0;
+            const int l = td.x + k, cam = ref_cam[lm2ref[lptr[l] + (slot - lrow0[l])]];
+            lo = min(lo, cam); hi = max(hi, cam);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
+    if (lane == 0) out[b] = make_int2(lo, hi);
+}
+
 // node.mu = initial estimate (gbp_ba.py:116,123); landmark records also carry their slot range
 __global__ __launch_bounds__(BLOCK) void k_init_vars(Params p, const double *__restrict__ cam_means, const double *__restrict__ lmk_means,
                                                      const int *__restrict__ lrow0, const int *__restrict__ lrow1)

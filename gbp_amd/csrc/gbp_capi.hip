@@ -232,8 +232,34 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
     // 5. per-slot data
     bool general_sweep = false;
     {
-        const int n_wg = std::max(1, std::min(T, n_cus));
+        int n_wg = std::max(1, std::min(T, n_cus));
+        if (const char *nb = getenv("GBP_FUSED_BLOCKS")) n_wg = std::max(1, std::min(n_wg, atoi(nb)));      // (experiment switch, as in fused_plan)
         const int cgmax = fused_max_cams();      // (host arithmetic on the LDS budget: gbp_fused_plan.hpp)
+        // Camera WINDOWS.  Workgroup b of the fused sweep walks the tiles [b T / n, (b + 1) T / n) and needs table rows for the cameras
+        // of THOSE tiles only.  In a sequence -- landmarks numbered along the trajectory, each seen from neighbouring cameras -- that is
+        // a short interval [lo, hi] however many cameras the graph has: the table becomes [hi - lo + 1][27] per workgroup, more cameras
+        // than fit the LDS as a whole still run the fused sweep, and the tables written and reduced every sweep shrink from
+        // workgroups x cameras rows to the sum of the windows.  Taken when the whole table would not fit, or when the windows add up to
+        // less than half of it; GBP_WINDOWS=0 / 1: never / whenever they fit.
+        h->wg_cam_range.clear();
+        long long rows = (long long)n_wg * C;
+        int max_window = 0;
+        if (T > 0 && C > 0 && !(h->flags & GBP_FLAG_NO_FUSED) && p.num_undamped != 0) {
+            int2 *d_rng = nullptr;
+            CHK(scratch_alloc(h, scratch, &d_rng, (size_t)n_wg));
+            hipLaunchKernelGGL(k_wg_cam_range, dim3((n_wg + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, h->stream, d_tiles, d_lrow0, lptr, lm2ref,
+                               h->d_ref_cam, T, n_wg, d_rng);
+            HIPCHK(hipGetLastError());
+            std::vector<int2> rng((size_t)n_wg);
+            HIPCHK(hipMemcpyAsync(rng.data(), d_rng, sizeof(int2) * (size_t)n_wg, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            long long sum = 0;
+            for (const int2 &r : rng) { const int w = r.y >= r.x ? r.y - r.x + 1 : 0; sum += w; max_window = std::max(max_window, w); }
+            const char *e = getenv("GBP_WINDOWS");
+            const bool want = e ? atoi(e) != 0 : (C > cgmax || 2 * sum <= rows);
+            if (want && max_window <= cgmax) { h->wg_cam_range = std::move(rng); rows = sum; }
+        }
+        const bool windowed = !h->wg_cam_range.empty();
         // Few factors per camera: the fused sweep writes (and its reduce reads back) one 224-byte table row per camera and WORKGROUP
         // whatever the graph's size, the staged form one 128-byte row per FACTOR.  Below ~0.75 factors per (workgroup, camera) the
         // staged sweep is the faster one -- 13k / 30k / 60k / 90k factors x 500 cameras: 18.6 / 20.5 / 24.2 / 29.1 against 26.3 /
@@ -243,12 +269,13 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         // per pair) runs 13.9 us fused against ~16 staged, so the threshold stays below 1.  GBP_STAGED_BELOW overrides it (0: never).
         double staged_below = 0.75;
         if (const char *e = getenv("GBP_STAGED_BELOW")) staged_below = atof(e);
-        const bool sparse = (double)F < staged_below * (double)n_wg * (double)C;
+        const bool sparse = (double)F < staged_below * (double)rows;      // (windows: the rows the tables really have)
         h->staged_auto = sparse && !(h->flags & (GBP_FLAG_FORCE_FUSED | GBP_FLAG_NO_FUSED));
         if (h->staged_auto) h->flags |= GBP_FLAG_NO_FUSED;
-        general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || C > cgmax;   // its staging buffer is streamed every sweep too
+        if (h->flags & GBP_FLAG_NO_FUSED) h->wg_cam_range.clear();
+        general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || (C > cgmax && !windowed);   // its staging buffer is streamed every sweep too
         const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0) + (p.loss != 0 ? 1 : 0)) * sizeof(double) + S * sizeof(int)
-                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)n_wg * std::max(C, 1) * TROW * sizeof(double)
+                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)std::max<long long>(rows, 1) * (TROW * sizeof(double) + sizeof(int)) + (size_t)n_wg * sizeof(int4) + (size_t)std::max(C, 1) * sizeof(int2) + 3 * 4096
                           + (size_t)std::max(C, 1) * (CAMREC + CBEL + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
                           + (size_t)(n_wg + 1) * sizeof(int) + (h->pack_mode ? 2 * (size_t)std::max(T, 1) * PART_ROW * sizeof(double) : 0) + (64 << 12);
@@ -551,7 +578,8 @@ int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n)
     const int32_t v[GBP_PLAN_INFO_FIELDS] = {
         h->fused.enabled ? 1 : 0, h->staged_auto ? 1 : 0, h->fused.enabled ? h->fused.single : 0, h->fused.single_probe,
         pinned ? h->fused.args.pin : -1, h->fused.enabled ? h->fused.n_blocks : std::max(1, std::min(h->p.T, h->n_cus)), h->p.T,
-        h->pack_mode};
+        h->pack_mode, h->fused.enabled && h->fused.windowed ? h->fused.max_window : 0,
+        h->fused.enabled ? (int32_t)std::min<long long>(h->fused.windowed ? h->fused.table_rows : (long long)h->fused.n_blocks * h->p.C, INT32_MAX) : 0};
     for (int i = 0; i < n && i < GBP_PLAN_INFO_FIELDS; ++i) out[i] = v[i];
     return GBP_OK;
 }

@@ -142,7 +142,10 @@ GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int
 // the persistent loop, the late landmark beliefs, the addressing -- is shared with the fused sweep.  (Rounds 1-3 ran the general sweep
 // as one wave per tile, k_factor_tile: 107 us at 1M factors; that kernel now serves the stage-wise calls and the dense remainder.)
 constexpr int STAGED_WAVE_DOUBLES = WAVE_LDS_DOUBLES + WTILE * CSTAGE_PLAIN + WTILE / 2;      // messages | rows | cpos
-template <int LOSS, int NWAVES, bool STAGED = false, bool PINNED = false, bool SINGLE = false>      // PINNED: FusedArgs::pin is in force (graphs beyond the memory-side cache); SINGLE: see the accumulation
+// WINDOWED: the workgroup's LDS table covers only the cameras [lo, hi] its own tiles meet (FusedArgs::win) -- sequences, where a landmark
+// is seen by neighbouring cameras and the landmarks are numbered along the trajectory: any number of cameras, tables that shrink with
+// the windows (fused_plan).
+template <int LOSS, int NWAVES, bool STAGED = false, bool PINNED = false, bool SINGLE = false, bool WINDOWED = false>      // PINNED: FusedArgs::pin is in force (graphs beyond the memory-side cache); SINGLE: see the accumulation
 __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -155,6 +158,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     int *ctl = reinterpret_cast<int *>(smem + acc_even + NWAVES * PER_WAVE);   // {next, done}
     const int tid = threadIdx.x, lane = tid & 63;
     clk_begin(a.clk);
+    int cam_base = a.cam_base, cam_count = a.cam_count, row_off = 0;
+    if (WINDOWED) {
+        const int4 w = a.win[blockIdx.x];
+        cam_base = __builtin_amdgcn_readfirstlane(w.x); cam_count = __builtin_amdgcn_readfirstlane(w.y); row_off = __builtin_amdgcn_readfirstlane(w.z);
+    }
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
@@ -336,8 +344,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
-        const int cloc = cam - a.cam_base;
-        const bool mine = active && (unsigned)cloc < (unsigned)a.cam_count;
+        const int cloc = cam - cam_base;
+        const bool mine = active && (unsigned)cloc < (unsigned)cam_count;
         // Lanes of a tile that hit the same camera add in rank (= lane) order.  Few of them: one round per rank, one lane per camera in
         // every ds_add_f64.  Many (graphs with a few dozen cameras: fr1desk has 63, and up to eight factors of a tile on one of them):
         // ALL lanes in one instruction -- the LDS atomic unit applies the lanes that share an address in ascending lane order, which IS
@@ -364,10 +372,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     __syncthreads();
     GBP_PH_NOWAIT(10);                                     // waiting for the other waves of the workgroup
     // table layout [camera][workgroup][27]: 216-byte runs here, one contiguous 55 KB read per camera in k_cam_reduce_tree
-    for (int i = tid; i < (a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
+    for (int i = tid; i < (WINDOWED ? cam_count : a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
         const int c = i / (TROW / 2), k = 2 * (i - c * (TROW / 2));
         const double2 v = make_double2(acc[c * 27 + k], k + 1 < 27 ? acc[c * 27 + k + 1] : 0.0);
-        *reinterpret_cast<double2 *>(a.block_partials + ((size_t)(a.cam_base + c) * gridDim.x + blockIdx.x) * TROW + k) = v;
+        const size_t row = WINDOWED ? (size_t)a.rowidx[row_off + c] : (size_t)(cam_base + c) * gridDim.x + blockIdx.x;
+        *reinterpret_cast<double2 *>(a.block_partials + row * TROW + k) = v;
     }
     GBP_PH(11);                                            // table write-out
     GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
@@ -422,15 +431,18 @@ GBP_DEV double cam_reduce_sum(const double *__restrict__ src, int n_blocks, doub
     return s;
 }
 
+// cam_rows (camera windows, fused_plan): camera c's rows are block_partials[cam_rows[c].x .. + cam_rows[c].y) instead of [c n .. c n + n)
 __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const double *__restrict__ block_partials, int n_blocks,
-                                                                 double *__restrict__ partial, int finish, PeerOut peer, unsigned long long *clk)
+                                                                 double *__restrict__ partial, int finish, PeerOut peer, unsigned long long *clk,
+                                                                 const int2 *__restrict__ cam_rows)
 {
     __shared__ __attribute__((aligned(16))) double sh[RED_LDS_DOUBLES];
     const int c = blockIdx.x, tid = threadIdx.x;
     clk_begin(clk);
     double *tot = sh + (RED_PARTS + RED_G) * TROW;
     const double pri = tid < 27 ? p.cprior[(size_t)c * 27 + tid] : 0.0;      // (asked for ahead of the tables: one round trip less in the tail)
-    const double s = cam_reduce_sum<RED_THREADS>(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);
+    const int2 rows = cam_rows ? cam_rows[c] : make_int2(c * n_blocks, n_blocks);
+    const double s = cam_reduce_sum<RED_THREADS>(block_partials + (size_t)rows.x * TROW, rows.y, sh, tid);
     if (tid < 27) {
         partial[(size_t)c * 27 + tid] = s;
         tot[tid] = s + pri;
@@ -448,6 +460,46 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     }
 }
 
+// Camera windows leave a camera a handful of rows (those of the workgroups whose window holds it: two to five in a sequence, where
+// k_cam_reduce_tree's 1024 threads per camera took 43.7 us for 10 000 cameras): one WAVE per camera.  Lane (g, pair) = (lane / 14,
+// lane % 14), g < 4, adds the 16-byte piece `pair` of rows g, g + 4, ...; the four partial sums are added in the order of g.  Returns
+// entry `lane` (< 27) of the sum.  fused_plan picks this form when no camera has more than ROWS_WAVE_MAX rows.
+constexpr int ROWS_WAVE_MAX = 64;
+constexpr int ROWS_THREADS = 256;
+GBP_DEV double cam_rows_sum_wave(const double *__restrict__ src, int n_rows, int lane)
+{
+    const int g = lane / RED_PAIRS, pair = lane - g * RED_PAIRS;
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double sx = 0.0, sy = 0.0;
+    if (g < 4)
+        for (int r = g; r < n_rows; r += 4) { const double2 v = s2[(size_t)r * RED_PAIRS + pair]; sx += v.x; sy += v.y; }
+    double ax = sx, ay = sy;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) { ax += __shfl(sx, (lane + j * RED_PAIRS) & 63, 64); ay += __shfl(sy, (lane + j * RED_PAIRS) & 63, 64); }      // (meaningful in lanes < 14)
+    const double ex = __shfl(ax, lane >> 1, 64), ey = __shfl(ay, lane >> 1, 64);
+    return lane < 27 ? ((lane & 1) ? ey : ex) : 0.0;
+}
+
+__global__ __launch_bounds__(ROWS_THREADS) void k_cam_reduce_rows(Params p, const double *__restrict__ block_partials, const int2 *__restrict__ cam_rows,
+                                                                  double *__restrict__ partial, int finish, PeerOut peer, unsigned long long *clk)
+{
+    clk_begin(clk);
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (ROWS_THREADS / 64) + (threadIdx.x >> 6);
+    if (c >= p.C) return;
+    const double pri = lane < 27 ? p.cprior[(size_t)c * 27 + lane] : 0.0;
+    const int2 rows = cam_rows[c];
+    const double s = cam_rows_sum_wave(block_partials + (size_t)rows.x * TROW, rows.y, lane);
+    if (lane < 27) partial[(size_t)c * 27 + lane] = s;
+    if (peer.n) peer_push_row(peer, c, s, lane);
+    if (!finish) return;
+    const double tot = s + pri;
+    if (lane < 27) p.cbelief[(size_t)c * CBEL + lane] = tot;
+    double v[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = __shfl(tot, k, 64);
+    cam_belief_store(v, p.cbel + (size_t)c * CAMREC, lane);
+}
+
 // Sharded sweep with the peer-store exchange, everything after the sweep kernel in ONE launch: a small grid of persistent
 // workgroups first reduces and PUSHES all of its cameras (workgroup tables -> 27 sums -> row c of every rank's mailbox + tag),
 // then finishes them, one wave per camera: wait for the n_ranks tags of row c, add the parts in rank order, prior, mean | covariance.
@@ -459,21 +511,33 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
 // collective's launch and sync.
 constexpr int XCHG_THREADS = 256;
 constexpr int XCHG_BLOCKS = 2048;
+template <bool WAVE_ROWS>                                   // WAVE_ROWS: one wave per camera adds its few rows (camera windows, cam_rows_sum_wave)
 __global__ __launch_bounds__(XCHG_THREADS) void k_cam_reduce_xchg(Params p, const double *__restrict__ block_partials, int n_blocks,
-                                                                  double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk)
+                                                                  double *__restrict__ partial, PeerOut peer, PeerWait wait, unsigned long long *clk,
+                                                                  const int2 *__restrict__ cam_rows)
 {
     __shared__ __attribute__((aligned(16))) double sh[RED_LDS_DOUBLES];
     const int tid = threadIdx.x;
     clk_begin(clk);
-    for (int c = blockIdx.x; c < p.C; c += gridDim.x) {
-        const double s = cam_reduce_sum<XCHG_THREADS>(block_partials + (size_t)c * n_blocks * TROW, n_blocks, sh, tid);      // the same order as k_cam_reduce_tree: bitwise the same sums
-        if (tid < 64) {
-            if (tid < 27) partial[(size_t)c * 27 + tid] = s;
-            peer_push_row(peer, c, s, tid);
-        }
-        __syncthreads();                                     // sh is overwritten by the next camera
-    }
     const int wave = tid >> 6, lane = tid & 63;
+    if (WAVE_ROWS) {
+        for (int c = blockIdx.x * (XCHG_THREADS / 64) + wave; c < p.C; c += (XCHG_THREADS / 64) * gridDim.x) {
+            const int2 rows = cam_rows[c];
+            const double s = cam_rows_sum_wave(block_partials + (size_t)rows.x * TROW, rows.y, lane);      // the same order as k_cam_reduce_rows
+            if (lane < 27) partial[(size_t)c * 27 + lane] = s;
+            peer_push_row(peer, c, s, lane);
+        }
+    } else {
+        for (int c = blockIdx.x; c < p.C; c += gridDim.x) {
+            const int2 rows = cam_rows ? cam_rows[c] : make_int2(c * n_blocks, n_blocks);
+            const double s = cam_reduce_sum<XCHG_THREADS>(block_partials + (size_t)rows.x * TROW, rows.y, sh, tid);      // the same order as k_cam_reduce_tree: bitwise the same sums
+            if (tid < 64) {
+                if (tid < 27) partial[(size_t)c * 27 + tid] = s;
+                peer_push_row(peer, c, s, tid);
+            }
+            __syncthreads();                                 // sh is overwritten by the next camera
+        }
+    }
     for (int c = blockIdx.x + wave * gridDim.x; c < p.C; c += (XCHG_THREADS / 64) * gridDim.x) cam_finish_wave(p, nullptr, peer.n, 0, wait, c, lane);
 }
 
@@ -554,22 +618,67 @@ inline int single_probe(hipStream_t stream, int *mask)
 //  per sweep at C = 1000.  The general sweep's persistent STAGED form does the same graph in 127 us and has no camera limit: removed.)
 
 // Workgroup tile ranges + per-workgroup camera tables.
-inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_cus)
+// wg_range (n_range = workgroups, or 0): the workgroups' camera windows {lowest, highest camera of its tiles} -- build_graph's decision
+// (k_wg_cam_range); without them every workgroup's table covers all cameras.
+inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_cus, const int2 *wg_range = nullptr, int n_range = 0)
 {
     if (p.F == 0 || p.C == 0 || p.T == 0) return 0;
+    pl.n_blocks = std::max(1, std::min(p.T, n_cus));
+    if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
+    pl.windowed = (wg_range && n_range == pl.n_blocks) ? 1 : 0;
+    pl.rows_wave = 0;
     // the sweep's table shares the LDS with the waves' scratch: more cameras than fit run the general sweep (STAGED form of the same loop)
     const int cmax = fused_max_cams();
-    if (p.C > cmax) return 0;
-    pl.group_cams = p.C;
+    pl.max_window = 0;
+    size_t table_rows = (size_t)pl.n_blocks * p.C;
+    std::vector<int4> win;
+    std::vector<int2> cam_rows;
+    std::vector<int> rowidx;
+    if (pl.windowed) {
+        // The rows of block_partials stay CAMERA-major -- the reduce reads one contiguous run per camera -- but a camera has rows only
+        // for the workgroups whose window holds it, in workgroup order.
+        win.resize((size_t)pl.n_blocks); cam_rows.assign((size_t)p.C, make_int2(0, 0));
+        std::vector<int> diff((size_t)p.C + 1, 0);
+        table_rows = 0;
+        for (int b = 0; b < pl.n_blocks; ++b) {
+            const int lo = wg_range[b].x, n = wg_range[b].y >= lo ? wg_range[b].y - lo + 1 : 0;
+            if (n && (lo < 0 || lo + n > p.C)) return -1;
+            win[(size_t)b] = make_int4(n ? lo : 0, n, (int)table_rows, 0);
+            if (n) { diff[(size_t)lo] += 1; diff[(size_t)lo + n] -= 1; }
+            table_rows += (size_t)n;
+            pl.max_window = std::max(pl.max_window, n);
+        }
+        if (table_rows > (size_t)INT32_MAX) return -1;
+        int run = 0, first = 0;
+        for (int c = 0; c < p.C; ++c) { run += diff[(size_t)c]; cam_rows[(size_t)c] = make_int2(first, 0); first += run; }
+        rowidx.resize(std::max<size_t>(table_rows, 1));
+        for (int b = 0; b < pl.n_blocks; ++b)
+            for (int k = 0; k < win[(size_t)b].y; ++k) {
+                int2 &cr = cam_rows[(size_t)win[(size_t)b].x + k];
+                rowidx[(size_t)win[(size_t)b].z + k] = cr.x + cr.y++;
+            }
+        int most = 0;
+        for (const int2 &cr : cam_rows) most = std::max(most, cr.y);
+        const int wave_max = getenv("GBP_ROWS_WAVE_MAX") ? atoi(getenv("GBP_ROWS_WAVE_MAX")) : ROWS_WAVE_MAX;      // (tests: 0 keeps the tree form)
+        pl.rows_wave = most <= wave_max ? 1 : 0;            // few rows per camera: one wave adds them (k_cam_reduce_rows)
+    }
+    if ((pl.windowed ? pl.max_window : p.C) > cmax) { pl.windowed = 0; return 0; }
+    pl.group_cams = pl.windowed ? std::max(pl.max_window, 1) : p.C;
     pl.n_groups = 1;
     const int acc_doubles = pl.group_cams * 27;
     const size_t shmem = fused_shmem(pl.group_cams);
-    pl.n_blocks = std::max(1, std::min(p.T, n_cus));
-    if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
     double *d_bp = nullptr;                                 // (workgroup b walks tiles [b T / n_blocks, (b + 1) T / n_blocks): computed in the kernels)
-    if (fused_upload<double>(pl, &d_bp, nullptr, (size_t)pl.n_blocks * p.C * TROW, stream)) return -1;
+    pl.table_rows = (long long)table_rows;
+    if (fused_upload<double>(pl, &d_bp, nullptr, table_rows * TROW, stream)) return -1;
     pl.args = FusedArgs{};
     pl.args.block_partials = d_bp; pl.args.acc_doubles = acc_doubles; pl.args.cam_base = 0; pl.args.cam_count = std::min(p.C, pl.group_cams);
+    pl.d_cam_rows = nullptr;
+    if (pl.windowed) {
+        int4 *d_win = nullptr; int *d_rowidx = nullptr; int2 *d_cam_rows = nullptr;
+        if (fused_upload<int4>(pl, &d_win, win.data(), win.size(), stream) || fused_upload<int>(pl, &d_rowidx, rowidx.data(), rowidx.size(), stream) ||
+            fused_upload<int2>(pl, &d_cam_rows, cam_rows.data(), cam_rows.size(), stream)) return -1;
+        pl.args.win = d_win; pl.args.rowidx = d_rowidx; pl.d_cam_rows = d_cam_rows;
+    }
 #if defined(GBP_FUSED_DBG_SWITCHES) || defined(GBP_PHASE_TIMING)
     if (instrument_plan(pl, stream)) return -1;             // experimental/gbp_instrument.hpp: GBP_FUSED_DBG, the phase buffer
 #endif
@@ -582,7 +691,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
         // WORSE below the cache size (71.3 against 67.3 at 1.1M): profiles/r04_size_sweep.jsonl, EXPERIMENTS.md.  The split is
         // per workgroup so that all of them finish together.
         const double S = (double)p.T * WTILE, MiB = 1024.0 * 1024.0;
-        const double fixed = (double)pl.n_blocks * p.C * TROW * 8 + (double)p.C * (CAMREC + CBEL + 27) * 8;
+        const double fixed = (double)table_rows * TROW * 8 + (double)p.C * (CAMREC + CBEL + 27) * 8;
         const double touched = S * (LIN_ROWS + MSG_ROWS) * 8 + S * 8 + (double)p.L * LREC * 8 + fixed;
         const double per_tile = WTILE * (LIN_ROWS + MSG_ROWS) * 8.0 + (double)p.L * LREC * 8 / std::max(p.T, 1);
         // (the share that pays shrinks with the distance from the cache size: 200 MiB just beyond it -- 67.1 against 70.7 ps per factor at
@@ -593,7 +702,7 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
         pl.args.pin = 0x7fffffff;
         if (keep_mib >= 0.0) pl.args.pin = (int)(std::max(0.0, keep_mib * MiB - fixed) / per_tile / pl.n_blocks);
         // few cameras: many factors of a 60-factor tile share one (fr1desk: 63 cameras, up to eight) -- the SINGLE variant of the accumulation
-        pl.single = getenv("GBP_ACC_SINGLE") ? atoi(getenv("GBP_ACC_SINGLE")) : (p.C <= (pl.args.pin != 0x7fffffff ? 200 : 350) ? 1 : 0);      // (1M factors: 66.1 against 75.1 us per step at 64 cameras, 68.0 / 72.4 at 128, 69.7 / 71.6 at 200, 72.7 / 73.4 at 300, equal at 400, 75.2 / 74.3 at 500; beyond the cache size -- the pinned variant -- 2M factors: 135.4 / 148.3 at 100 cameras, 151.0 / 143.7 at 300)
+        pl.single = getenv("GBP_ACC_SINGLE") ? atoi(getenv("GBP_ACC_SINGLE")) : (pl.group_cams <= (pl.args.pin != 0x7fffffff ? 200 : 350) ? 1 : 0);      // (1M factors: 66.1 against 75.1 us per step at 64 cameras, 68.0 / 72.4 at 128, 69.7 / 71.6 at 200, 72.7 / 73.4 at 300, equal at 400, 75.2 / 74.3 at 500; beyond the cache size -- the pinned variant -- 2M factors: 135.4 / 148.3 at 100 cameras, 151.0 / 143.7 at 300)
         if (pl.single) {                                    // the order SINGLE relies on is verified on this device before it is used (single_probe)
             pl.single_probe = single_probe(stream, &pl.single_probe_mask);
             if (pl.single_probe < 0) return -1;
@@ -614,6 +723,12 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, true>))
+    if (pl.windowed) {
+        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, false, true>))
+        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, false, true>))
+        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true, true>))
+        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, true, true>))
+    }
 #undef GBP_SET_SHMEM
     pl.enabled = true;
     return 0;
@@ -631,7 +746,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
     if (e0) (void)hipEventRecord(e0, stream);
     const bool pinned = pl.args.pin != 0x7fffffff;
-    switch (p.loss + (pinned ? 4 : 0) + (pl.single ? 8 : 0)) {
+    switch (p.loss + (pinned ? 4 : 0) + (pl.single ? 8 : 0) + (pl.windowed ? 16 : 0)) {
     case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 2: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
@@ -643,7 +758,19 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     case 10: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 12: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     case 13: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 14: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 16: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 17: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 18: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 20: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 21: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 22: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 24: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 25: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 26: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 28: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    case 29: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
+    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
     }
     if (e1) (void)hipEventRecord(e1, stream);
     if (p.parts && !defer_big) hipLaunchKernelGGL(k_lmk_finish_parts, dim3((p.T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, p);
@@ -656,18 +783,28 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
         int xb = pl.xchg_blocks;
         if (xb == 0) {
             int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_cam_reduce_xchg), XCHG_THREADS, red_shmem) != hipSuccess ||
+            const void *fn = pl.rows_wave ? reinterpret_cast<const void *>(&k_cam_reduce_xchg<true>) : reinterpret_cast<const void *>(&k_cam_reduce_xchg<false>);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, XCHG_THREADS, red_shmem) != hipSuccess ||
                 hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
                 return (int)hipErrorUnknown;
             xb = std::min(XCHG_BLOCKS, per_cu * cus);
             if (const char *e = getenv("GBP_XCHG_BLOCKS")) xb = std::max(1, std::min(xb, atoi(e)));
             pl.xchg_blocks = xb;
         }
-        hipLaunchKernelGGL(k_cam_reduce_xchg, dim3(std::min(p.C, xb)), dim3(XCHG_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial,
-                           po, *merged, clk ? clk + 2 : nullptr);
+        if (pl.rows_wave)
+            hipLaunchKernelGGL(k_cam_reduce_xchg<true>, dim3(std::min((p.C + XCHG_THREADS / 64 - 1) / (XCHG_THREADS / 64), xb)), dim3(XCHG_THREADS), red_shmem, stream, p,
+                               pl.args.block_partials, pl.n_blocks, partial, po, *merged, clk ? clk + 2 : nullptr, pl.d_cam_rows);
+        else
+            hipLaunchKernelGGL(k_cam_reduce_xchg<false>, dim3(std::min(p.C, xb)), dim3(XCHG_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial,
+                               po, *merged, clk ? clk + 2 : nullptr, pl.d_cam_rows);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po, clk ? clk + 2 : nullptr);
+    if (pl.rows_wave) {
+        hipLaunchKernelGGL(k_cam_reduce_rows, dim3((p.C + ROWS_THREADS / 64 - 1) / (ROWS_THREADS / 64)), dim3(ROWS_THREADS), 0, stream, p, pl.args.block_partials,
+                           pl.d_cam_rows, partial, finish, po, clk ? clk + 2 : nullptr);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_cam_reduce_tree, dim3(p.C), dim3(RED_THREADS), red_shmem, stream, p, pl.args.block_partials, pl.n_blocks, partial, finish, po, clk ? clk + 2 : nullptr, pl.d_cam_rows);
     return (int)hipGetLastError();
 }
 

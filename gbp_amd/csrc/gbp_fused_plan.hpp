@@ -42,7 +42,8 @@ constexpr int NPHASE = 12;          // marks of the phase profile (experimental/
 #endif
 
 struct FusedArgs {
-    double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes
+    double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes (WINDOWED: the rows of a
+                                // camera are those of the workgroups whose camera window holds it, in workgroup order: FusedPlan::d_cam_rows)
     int acc_doubles;            // cameras of the group * 27
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
     int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
@@ -53,6 +54,8 @@ struct FusedArgs {
                                 // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
     int pin;                    // the first `pin` tiles of every workgroup's range use the memory-side cache as `nt` says; the rest stream
                                 // PAST it altogether, loads and message stores (fused_plan: graphs beyond the cache size)
+    const int4 *win;            // WINDOWED: per workgroup {first camera of its table, cameras in it, offset into rowidx, -}, else NULL
+    const int *rowidx;          // WINDOWED: rowidx[offset + k] = the row of block_partials workgroup b's local camera k is written to
     int full_rows;              // STAGED: write whole camera-message rows (the staged x0 halves cannot be trusted: first staged sweep after
                                 // create / restore / a sweep of another kind); else only tiles in which a factor relinearised do
 };
@@ -62,6 +65,10 @@ struct FusedPlan {
     int n_groups = 0, group_cams = 0;                // (one camera group: the whole table in LDS)
     int n_blocks = 0;
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
+    long long table_rows = 0;                        // rows of block_partials
+    int windowed = 0, max_window = 0;                // camera WINDOWS: every workgroup's table covers the cameras [lo, hi] its tiles meet (fused_plan)
+    int rows_wave = 0;                               // windowed and no camera has more than ROWS_WAVE_MAX rows: the reduce runs one wave per camera
+    const int2 *d_cam_rows = nullptr;                // windowed: per camera {first row, rows} of block_partials, else NULL (camera c: rows c n .. c n + n - 1)
     int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
     int single_probe = -1;                           // -1: SINGLE not wanted, no probe; 1: the device's lane order was verified; 0: it failed, rounds variant instead
     int single_probe_mask = 0;                       // failing patterns of k_single_probe

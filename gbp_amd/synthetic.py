@@ -86,8 +86,13 @@ def _look_at_cameras(rng, n, target_jitter, r_lo, r_hi):
 
 def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK_K,
                    width=640.0, height=480.0, pix_noise=1.0, cam_t_noise=0.02,
-                   ball_radius=2.0, shell=(5.0, 6.0), target_jitter=0.2, min_depth=0.5):
-    """Generate a BA problem with exactly n_lmks*obs_per_lmk factors (camera-major order)."""
+                   ball_radius=2.0, shell=(5.0, 6.0), target_jitter=0.2, min_depth=0.5, window=None):
+    """Generate a BA problem with exactly n_lmks*obs_per_lmk factors (camera-major order).
+
+    window = w: a SEQUENCE instead of the headline graph's all-see-all -- every landmark is seen by obs_per_lmk cameras out of w
+    consecutive ones, and the landmarks are numbered along the trajectory (by the centre of their window), the way a SLAM front end
+    or an incremental reconstruction numbers them (the reference's fr1desk files: a landmark's cameras span 2 .. 46 consecutive
+    keyframes).  The default (None) is the graph of BASELINE configs 4-5 and draws exactly the random numbers it always drew."""
     if obs_per_lmk > n_cams:
         raise ValueError("obs_per_lmk cannot exceed n_cams")
     rng = np.random.default_rng(seed)
@@ -108,8 +113,11 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
     R_cw = rodrigues(w_cw)  # the rotation the engine will actually reconstruct
 
     # landmarks + visibility, chunked so that memory stays bounded at 100k x 500
+    if window is not None and not obs_per_lmk <= window <= n_cams:
+        raise ValueError("window must lie between obs_per_lmk and n_cams")
     lmk = np.empty((n_lmks, 3))
     chosen = np.empty((n_lmks, obs_per_lmk), dtype=np.int32)
+    centre = np.empty(n_lmks)
     done = 0
     chunk = 8192
     stalls = 0
@@ -124,6 +132,9 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
         u = fx * pc[..., 0] / zs + cx
         vv = fy * pc[..., 1] / zs + cy
         vis = (z > min_depth) & (u >= 0) & (u < width) & (vv >= 0) & (vv < height)
+        if window is not None:
+            ctr = rng.uniform(window / 2.0, n_cams - window / 2.0, size=m)
+            vis &= np.abs(np.arange(n_cams)[None, :] + 0.5 - ctr[:, None]) <= window / 2.0
         keys = np.where(vis, rng.uniform(size=vis.shape), 2.0)
         pick = np.argpartition(keys, obs_per_lmk - 1, axis=1)[:, :obs_per_lmk]
         good = np.take_along_axis(keys, pick, axis=1).max(axis=1) < 1.5
@@ -135,7 +146,12 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
         sel = np.nonzero(good)[0][:k]
         lmk[done:done + k] = pts[sel]
         chosen[done:done + k] = np.sort(pick[sel], axis=1)
+        if window is not None:
+            centre[done:done + k] = ctr[sel]
         done += k
+    if window is not None:                                   # numbered along the trajectory
+        along = np.argsort(centre, kind='stable')
+        lmk, chosen = lmk[along], chosen[along]
 
     cam_idx = chosen.reshape(-1)
     lmk_idx = np.repeat(np.arange(n_lmks, dtype=np.int32), obs_per_lmk)

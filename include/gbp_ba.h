@@ -240,12 +240,15 @@ int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_b
  * workgroup that keep using the memory-side cache (-1: all of them); [5] workgroups; [6] tiles; [7] tile packing: 0 every landmark
  * inside one 64-slot tile, 1 the same with the landmarks above 64 factors cut into chunk tiles, 2 dense (tile t = factors [64 t, 64 t + 64)
  * of the landmark-major list: chosen when whole landmarks would leave more than 15 % of the slots empty and every landmark has at
- * least three factors).  From 1 on some landmarks span tiles: their beliefs are formed by a small kernel after the sweep. */
-#define GBP_PLAN_INFO_FIELDS 8
+ * least three factors).  From 1 on some landmarks span tiles: their beliefs are formed by a small kernel after the sweep; [8] camera
+ * windows: the widest per-workgroup camera table of the fused sweep (each workgroup's table covers only the interval of cameras its own
+ * tiles meet: sequences, where that interval is short however many cameras there are), 0 = every table covers all cameras; [9] rows
+ * of all tables together (windows: their sum; else workgroups x cameras), 0 under the general sweep. */
+#define GBP_PLAN_INFO_FIELDS 10
 int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n);
 int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols);   /* debug builds with -DGBP_PHASE_TIMING only (tools/phase_profile.py): per-wave time per phase of the last fused sweep */
 int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots);   /* debug: slots whose (camera, landmark) do not match the reference factor they hold (0 = sound) */
-int gbp_ba_fused_max_cams(void);    /* most cameras of the fused sweep (camera table + wave scratch in 160 KB of LDS); above it the general sweep runs */
+int gbp_ba_fused_max_cams(void);    /* most cameras of ONE workgroup's table in the fused sweep (camera table + wave scratch in 160 KB of LDS); graphs above it run the general sweep unless their camera windows fit (gbp_ba_plan_info [8]) */
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,97 @@ def test_sparse_graphs_take_the_staged_sweep(oracle_mod, monkeypatch):
     assert e.info()['cam_groups'] == 1 and gap < BELIEF_TOL, (e.info(), gap)
 
 
+@pytest.mark.parametrize('n_cams,window,obs,loss,single', [(2000, 12, 6, None, None), (2000, 12, 6, 'huber', '0'), (3000, 40, 10, 'constant', None),
+                                                          (1500, 64, 40, None, None), (300, 10, 5, None, None)])
+def test_camera_windows_of_a_sequence(oracle_mod, monkeypatch, n_cams, window, obs, loss, single):
+    """A sequence: every landmark is seen from `obs` of `window` consecutive cameras, landmarks numbered along the trajectory.  The cameras
+    of a workgroup's tiles form a short interval, so the fused sweep runs with per-workgroup camera WINDOWS -- with thousands of cameras,
+    far beyond what one LDS table holds -- and gives the oracle's beliefs, messages and relinearisation ages (both accumulation variants,
+    the robust losses, the dense packing at 40 factors per landmark, and a graph whose whole table WOULD fit but whose windows are
+    much smaller)."""
+    from gbp_amd import _capi
+    cmax = _capi.load().gbp_ba_fused_max_cams()
+    monkeypatch.delenv('GBP_WINDOWS', raising=False)
+    if single is None:
+        monkeypatch.delenv('GBP_ACC_SINGLE', raising=False)
+    else:
+        monkeypatch.setenv('GBP_ACC_SINGLE', single)
+    n_lmks = 36_000 // obs
+    prob = make_synthetic(n_cams=n_cams, n_lmks=n_lmks, obs_per_lmk=obs, seed=5, window=window)
+    kw = dict(loss=loss, Nstds=2.0) if loss else {}
+    from gbp_amd.engine import BAEngine
+    o = oracle_mod.OracleBA.from_problem(prob, threads=8, **kw)
+    e = BAEngine.from_problem(prob, **kw)
+    pi = e.plan_info()
+    assert pi['fused'] and not pi['staged_by_sparseness'], pi
+    assert 0 < pi['max_window'] <= min(cmax, 3 * window + n_cams // 64), pi
+    assert pi['table_rows'] < pi['n_blocks'] * n_cams // 2, pi
+    assert pi['single'] == (single != '0'), pi
+    if obs == 40:
+        assert pi['pack_mode'] == 2, pi
+    for g in (o, e):
+        g.generate_priors_var(50.0)
+        g.update_all_beliefs()
+        oracle_mod.replay_ba(g, 14)
+    assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
+    gap = max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs()))
+    assert gap < BELIEF_TOL, gap
+    for a, b in zip(e.messages(), o.messages()):
+        assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+    before = [a.copy() for a in e.beliefs()]
+    e.update_all_beliefs()
+    for a, b in zip(e.beliefs(), before):
+        assert rel_err_rows(a, b) < 1e-9
+    assert e.check_layout() == 0 and e.are() == pytest.approx(o.are(), rel=1e-6)
+    e.close()
+
+
+def test_camera_windows_switch_and_fallbacks(oracle_mod, monkeypatch):
+    """GBP_WINDOWS=0: whole tables (the same beliefs to rounding: only the order of the per-camera sums over workgroups differs);
+    a sequence whose windows do not fit the LDS runs the general sweep; cameras nobody observes (no window holds them: no table row)
+    keep their priors."""
+    from gbp_amd import _capi
+    from gbp_amd.engine import BAEngine
+    cmax = _capi.load().gbp_ba_fused_max_cams()
+    prob = make_synthetic(n_cams=300, n_lmks=7000, obs_per_lmk=5, seed=9, window=10)
+    out = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('GBP_WINDOWS', sw)
+        e = BAEngine.from_problem(prob, fused=None if sw == '1' else True)      # (whole tables: 35 000 factors on 256 x 300 table rows are sparse, the staged sweep would run)
+        assert (e.plan_info()['max_window'] > 0) == (sw == '1') and e.plan_info()['fused'], e.plan_info()
+        e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(12)
+        out[sw] = e.beliefs()
+        e.close()
+    assert max(rel_err_rows(a, b) for a, b in zip(out['1'], out['0'])) < 1e-10
+    # the reduce behind the windows: one wave per camera (a handful of rows each), or -- a camera with more than 64 rows -- the tree
+    monkeypatch.setenv('GBP_WINDOWS', '1')
+    monkeypatch.setenv('GBP_ROWS_WAVE_MAX', '0')
+    e = BAEngine.from_problem(prob)
+    e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(12)
+    assert e.plan_info()['max_window'] > 0 and max(rel_err_rows(a, b) for a, b in zip(out['1'], e.beliefs())) < 1e-10
+    e.close()
+    monkeypatch.delenv('GBP_ROWS_WAVE_MAX')
+    monkeypatch.delenv('GBP_WINDOWS')
+    wide = make_synthetic(n_cams=2 * cmax, n_lmks=3000, obs_per_lmk=6, seed=9, window=cmax + 200)
+    gap, o, e = run_pair(oracle_mod, wide, n_sweeps=8)
+    assert not e.plan_info()['fused'] and e.plan_info()['max_window'] == 0 and gap < BELIEF_TOL, (e.plan_info(), gap)
+    e.close()
+    # cameras 0..49 and the last 50 of 2100 have no factor
+    seq = make_synthetic(n_cams=2000, n_lmks=6000, obs_per_lmk=6, seed=2, window=12)
+    prob = BAProblem(K=seq.K, cam_means=np.concatenate([seq.cam_means[:50], seq.cam_means, seq.cam_means[-50:]]), lmk_means=seq.lmk_means,
+                     meas=seq.meas, cam_idx=(seq.cam_idx + 50).astype(np.int32), lmk_idx=seq.lmk_idx)
+    e = BAEngine.from_problem(prob)
+    o = oracle_mod.OracleBA.from_problem(prob, threads=8)
+    cov = [np.eye(6) * 1e-2] * prob.n_cams + [np.eye(3) * 1e-1] * prob.n_lmks
+    e.set_priors_var(cov); o.set_priors_var(cov[:prob.n_cams], cov[prob.n_cams:])
+    for g in (e, o):
+        g.update_all_beliefs()
+        g.iterate(8)
+    assert e.plan_info()['max_window'] > 0, e.plan_info()
+    assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())) < BELIEF_TOL
+    e.close()
+
+
 def test_tiles_past_the_memory_side_cache_change_nothing(monkeypatch):
     """Graphs beyond the 256 MiB memory-side cache run the pinned variant of the fused sweep (FusedArgs::pin: the first tiles of a
     workgroup keep using the cache, the rest stream past it with nontemporal loads and stores).  Cache hints only: forced on a

@@ -104,7 +104,7 @@ def run_world(problem, world, fused, n_sweeps, oracle_mod, library_loop=True):
             ares, energies = oracle_mod.replay_ba(g, n_sweeps, diagnostics=True)
             ce, cl = g.camera_beliefs()
             rng, le, ll = g.local_landmark_beliefs()
-            out[r] = dict(ce=ce, cl=cl, le=le, ll=ll, rng=rng, ares=ares, energies=energies, F=g.F, fused=g.info()['fused'])
+            out[r] = dict(ce=ce, cl=cl, le=le, ll=ll, rng=rng, ares=ares, energies=energies, F=g.F, fused=g.info()['fused'], plan=g.engine.plan_info())
         except BaseException as e:                           # noqa: BLE001 -- surface it in the main thread
             errors.append(e)
             shared.barrier.abort()
@@ -340,6 +340,37 @@ def test_sharded_with_landmarks_that_span_tiles(oracle_mod, fused, obs):
     ranks = run_world(p, 2, fused, 14, oracle_mod, True)
     lo = 0
     for r in ranks:
+        assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])
+        assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
+        a, b = r['rng']
+        assert a == lo
+        lo = b
+        assert rel_err_rows(r['le'], rle[a:b]) < 1e-6 and rel_err_rows(r['ll'], rll[a:b]) < 1e-6
+        assert np.allclose(r['ares'], ares, rtol=1e-7)
+    assert lo == p.n_lmks
+
+
+@pytest.mark.parametrize('library_loop,wave_rows', [(True, True), (False, True), (True, False)])
+def test_sharded_sequence_with_camera_windows(oracle_mod, monkeypatch, library_loop, wave_rows):
+    """A sequence of 1 500 cameras in two landmark shards: each rank's fused sweep runs with per-workgroup camera windows (far more cameras
+    than one LDS table holds), and the merged reduce-exchange-finish launch reads a camera's rows through the same per-camera row ranges.
+    Against one engine on the whole graph."""
+    from gbp_amd.engine import BAEngine
+    if wave_rows:
+        monkeypatch.delenv('GBP_ROWS_WAVE_MAX', raising=False)       # one wave per camera adds its few rows
+    else:
+        monkeypatch.setenv('GBP_ROWS_WAVE_MAX', '0')                 # the tree form, as for a camera with many rows
+    p = make_synthetic(n_cams=1500, n_lmks=6000, obs_per_lmk=6, seed=31, window=14)
+    ref = BAEngine.from_problem(p)
+    assert ref.plan_info()['fused'] and ref.plan_info()['max_window'] > 0, ref.plan_info()
+    ref.generate_priors_var(50.0)
+    ref.update_all_beliefs()
+    ares, energies = oracle_mod.replay_ba(ref, 14, diagnostics=True)
+    rce, rcl, rle, rll = ref.beliefs()
+    ranks = run_world(p, 2, None, 14, oracle_mod, library_loop)
+    lo = 0
+    for r in ranks:
+        assert r['plan']['fused'] and r['plan']['max_window'] > 0, r['plan']
         assert np.array_equal(r['ce'], ranks[0]['ce']) and np.array_equal(r['cl'], ranks[0]['cl'])
         assert rel_err_rows(r['ce'], rce) < 1e-6 and rel_err_rows(r['cl'], rcl) < 1e-6
         a, b = r['rng']
