@@ -463,8 +463,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
 // Camera windows leave a camera a handful of rows (those of the workgroups whose window holds it: two to five in a sequence, where
 // k_cam_reduce_tree's 1024 threads per camera took 43.7 us for 10 000 cameras): one WAVE per camera.  Lane (g, pair) = (lane / 14,
 // lane % 14), g < 4, adds the 16-byte piece `pair` of rows g, g + 4, ...; the four partial sums are added in the order of g.  Returns
-// entry `lane` (< 27) of the sum.  fused_plan picks this form when no camera has more than ROWS_WAVE_MAX rows.
-constexpr int ROWS_WAVE_MAX = 64;
+// entry `lane` (< 27) of the sum.  fused_plan picks this form when the cameras have at most ROWS_WAVE_MAX rows on average (fr1desk_small
+// with windows forced: 41 rows per camera, 5.1 us in this form against 3.6 in the tree form).
+constexpr int ROWS_WAVE_MAX = 16;
 constexpr int ROWS_THREADS = 256;
 GBP_DEV double cam_rows_sum_wave(const double *__restrict__ src, int n_rows, int lane)
 {
@@ -472,7 +473,13 @@ GBP_DEV double cam_rows_sum_wave(const double *__restrict__ src, int n_rows, int
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
     double sx = 0.0, sy = 0.0;
     if (g < 4)
-        for (int r = g; r < n_rows; r += 4) { const double2 v = s2[(size_t)r * RED_PAIRS + pair]; sx += v.x; sy += v.y; }
+        for (int r0 = g; r0 < n_rows; r0 += 32) {           // eight loads in flight per lane, added in row order
+            double2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int r = r0 + 4 * j; v[j] = r < n_rows ? s2[(size_t)r * RED_PAIRS + pair] : make_double2(0.0, 0.0); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sx += v[j].x; sy += v[j].y; }
+        }
     double ax = sx, ay = sy;
 #pragma unroll
     for (int j = 1; j < 4; ++j) { ax += __shfl(sx, (lane + j * RED_PAIRS) & 63, 64); ay += __shfl(sy, (lane + j * RED_PAIRS) & 63, 64); }      // (meaningful in lanes < 14)
@@ -657,10 +664,10 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
                 int2 &cr = cam_rows[(size_t)win[(size_t)b].x + k];
                 rowidx[(size_t)win[(size_t)b].z + k] = cr.x + cr.y++;
             }
-        int most = 0;
-        for (const int2 &cr : cam_rows) most = std::max(most, cr.y);
+        // few rows per camera ON AVERAGE: one wave adds them (k_cam_reduce_rows).  A wave takes 32 rows per round trip, so one camera
+        // with many rows costs that launch microseconds where the tree form costs every camera a 1024-thread workgroup.
         const int wave_max = getenv("GBP_ROWS_WAVE_MAX") ? atoi(getenv("GBP_ROWS_WAVE_MAX")) : ROWS_WAVE_MAX;      // (tests: 0 keeps the tree form)
-        pl.rows_wave = most <= wave_max ? 1 : 0;            // few rows per camera: one wave adds them (k_cam_reduce_rows)
+        pl.rows_wave = table_rows <= (size_t)wave_max * (size_t)p.C ? 1 : 0;
     }
     if ((pl.windowed ? pl.max_window : p.C) > cmax) { pl.windowed = 0; return 0; }
     pl.group_cams = pl.windowed ? std::max(pl.max_window, 1) : p.C;

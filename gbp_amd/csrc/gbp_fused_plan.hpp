@@ -67,7 +67,7 @@ struct FusedPlan {
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     long long table_rows = 0;                        // rows of block_partials
     int windowed = 0, max_window = 0;                // camera WINDOWS: every workgroup's table covers the cameras [lo, hi] its tiles meet (fused_plan)
-    int rows_wave = 0;                               // windowed and no camera has more than ROWS_WAVE_MAX rows: the reduce runs one wave per camera
+    int rows_wave = 0;                               // windowed and at most ROWS_WAVE_MAX rows per camera on average: the reduce runs one wave per camera
     const int2 *d_cam_rows = nullptr;                // windowed: per camera {first row, rows} of block_partials, else NULL (camera c: rows c n .. c n + n - 1)
     int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
     int single_probe = -1;                           // -1: SINGLE not wanted, no probe; 1: the device's lane order was verified; 0: it failed, rounds variant instead

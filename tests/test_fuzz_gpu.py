@@ -103,7 +103,19 @@ def test_random_shapes_dense_packing(oracle_mod, monkeypatch, seed):
     run_seed(oracle_mod, 100_000 + seed, random_problem(seed, min_deg=3), seed)
 
 
-def run_seed(oracle_mod, key, p, seed):
+@pytest.mark.parametrize('seed', range(max(1, N_SEEDS // 2)))
+def test_random_shapes_camera_windows(oracle_mod, monkeypatch, seed):
+    """The same comparison with per-workgroup camera windows asked for wherever they fit (GBP_WINDOWS=1): every workgroup's table covers
+    the interval of cameras its own tiles meet, whatever its width -- here one or a few tiles per workgroup on 2 .. 40 random cameras --
+    and the reduce adds a camera's rows through the per-camera row ranges (odd seeds: its tree form, and the dense packing)."""
+    monkeypatch.setenv('GBP_WINDOWS', '1')
+    if seed % 2:
+        monkeypatch.setenv('GBP_ROWS_WAVE_MAX', '0')
+        monkeypatch.setenv('GBP_PACK', 'dense')
+    run_seed(oracle_mod, 200_000 + seed, random_problem(seed, min_deg=3 if seed % 2 else 1), seed, want_windows=True)
+
+
+def run_seed(oracle_mod, key, p, seed, want_windows=False):
     from gbp_amd.engine import BAEngine
     rng = np.random.default_rng(seed)
     loss = [None, 'huber', 'constant'][seed % 3]
@@ -114,6 +126,8 @@ def run_seed(oracle_mod, key, p, seed):
     flags = [(bool(rng.integers(0, 2)), bool(rng.random() < 0.8)) for _ in range(8)]
     o = oracle_mod.OracleBA.from_problem(p, threads=4, **cfg)
     engines = [BAEngine.from_problem(p, fused=True, **cfg), BAEngine.from_problem(p, fused=False, **cfg)]
+    if want_windows:
+        assert engines[0].plan_info()['max_window'] > 0, engines[0].plan_info()
     for g in [o] + engines:
         g.generate_priors_var(30.0)
         g.update_all_beliefs()

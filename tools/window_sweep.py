@@ -5,7 +5,7 @@ the whole table fits the LDS, against whole tables (GBP_WINDOWS=0).  One bench.p
 (profiles/rNN_camera_windows.json).  Run on the GPU box."""
 import json, os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-shapes = [(500, 30, 10), (2000, 30, 10), (2000, 100, 10), (10000, 30, 10), (13682, 60, 5, 616000), (500, 30, 40)]
+shapes = [(500, 30, 10), (2000, 30, 10), (2000, 100, 10), (10000, 30, 10), (13682, 60, 5, 616000)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]]
 out = {}
