@@ -321,6 +321,7 @@ def main(shard_factory=None, script=None):
                     'consecutive cameras (make_synthetic(window=...)); the fused sweep then runs with per-workgroup camera windows')
     ap.add_argument('--bal', default=None, help='BAL text file instead of the synthetic graph (BASELINE configs 2-3, e.g. '
                                                 'tests/golden/data/fr1desk.txt); not the headline workload')
+    ap.add_argument('--closures', type=float, default=0.0, help='with --window: this fraction of the landmarks is seen from anywhere along the trajectory')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hbm-size', action='store_true', help='skip the 2M-factor replay behind roofline.frac_hbm_bound')
@@ -365,8 +366,8 @@ def main(shard_factory=None, script=None):
         workload = f"BAL file {os.path.basename(args.bal)}"
     else:
         from gbp_amd.synthetic import make_synthetic
-        problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0, window=args.window)
-        workload = "synthetic BAL" if args.window is None else f"synthetic sequence (window {args.window})"
+        problem = make_synthetic(n_cams=args.cams, n_lmks=args.lmks, obs_per_lmk=args.obs, seed=0, window=args.window, closures=args.closures)
+        workload = "synthetic BAL" if args.window is None else f"synthetic sequence (window {args.window}, closures {args.closures})"
     F, L, C = problem.n_factors, problem.n_lmks, problem.n_cams
 
     # one node: the collectives' bootstrap sockets need no NIC and no resolvable hostname (the data path is xGMI either way)
@@ -541,7 +542,7 @@ def main(shard_factory=None, script=None):
         travel together in one line."""
         from gbp_amd.engine import BAEngine
         from gbp_amd.synthetic import make_synthetic
-        big = make_synthetic(n_cams=args.cams, n_lmks=2 * args.lmks, obs_per_lmk=args.obs, seed=0, window=args.window)
+        big = make_synthetic(n_cams=args.cams, n_lmks=2 * args.lmks, obs_per_lmk=args.obs, seed=0, window=args.window, closures=args.closures)
         g = BAEngine.from_problem(big, device=local_rank)
         try:
             g.generate_priors_var(50.0); g.update_all_beliefs(); g.sync(); g.snapshot_state()

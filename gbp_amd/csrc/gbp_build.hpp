@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_tiles(Params p, BuildArgs a)
 }
 
 // out[b] = {lowest, highest} camera among the factors of the tiles that workgroup b of the fused sweep walks (tiles [b T / n, (b + 1) T / n),
-// k_sweep_wat): the workgroup's camera WINDOW (fused_plan).  One wave per workgroup, the slot -> factor decode of k_build_tiles.
+// k_sweep_wat): the interval its camera window lies in (k_wg_cam_sets, fused_plan).  One wave per workgroup, the slot -> factor decode of k_build_tiles.
 __global__ __launch_bounds__(BLOCK) void k_wg_cam_range(const int4 *__restrict__ tiles, const int *__restrict__ lrow0, const int *__restrict__ lptr,
                                                         const int *__restrict__ lm2ref, const int *__restrict__ ref_cam, int T, int n_wg,
                                                         int2 *__restrict__ out)
@@ -294,6 +294,50 @@ __global__ __launch_bounds__(BLOCK) void k_wg_cam_range(const int4 *__restrict__
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_down(lo, off, 64)); hi = max(hi, __shfl_down(hi, off, 64)); }
     if (lane == 0) out[b] = make_int2(lo, hi);
+}
+
+// The camera SET of workgroup b: the distinct cameras among the factors of its tiles, ascending, into lists[b * cap ..) (the first `cap`
+// of them) and their number into counts[b].  One 256-thread workgroup per workgroup of the sweep: a bitmap over its interval
+// rng[b] = [lo, hi] in LDS (dynamic: (widest interval + 31) / 32 + 257 words), then a compaction in index order.
+constexpr int SETS_THREADS = 256;
+__global__ __launch_bounds__(SETS_THREADS) void k_wg_cam_sets(const int4 *__restrict__ tiles, const int *__restrict__ lrow0, const int *__restrict__ lptr,
+                                                              const int *__restrict__ lm2ref, const int *__restrict__ ref_cam, int T, int n_wg,
+                                                              const int2 *__restrict__ rng, int cap, int *__restrict__ lists, int *__restrict__ counts)
+{
+    extern __shared__ unsigned bm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int lo = rng[b].x, width = rng[b].y >= lo ? rng[b].y - lo + 1 : 0, words = (width + 31) >> 5;
+    unsigned *scan = bm + words;
+    for (int i = tid; i < words; i += SETS_THREADS) bm[i] = 0u;
+    __syncthreads();
+    const int t0 = (int)((long long)b * T / n_wg), t1 = (int)((long long)(b + 1) * T / n_wg);
+    for (int t = t0 + (tid >> 6); t < t1; t += SETS_THREADS / 64) {
+        const int4 td = tiles[t];
+        const int slot = t * WTILE + lane;
+        if (lane < td.z) {
+            int k = 0;
+            for (int i = 1; i < td.y; ++i) k += (lrow0[td.x + i] <= slot) ? 1 : 0;
+            const int l = td.x + k, cam = ref_cam[lm2ref[lptr[l] + (slot - lrow0[l])]] - lo;
+            atomicOr(&bm[cam >> 5], 1u << (cam & 31));
+        }
+    }
+    __syncthreads();
+    const int per = (words + SETS_THREADS - 1) / SETS_THREADS, w0 = min(tid * per, words), w1 = min(w0 + per, words);
+    int n = 0;
+    for (int w = w0; w < w1; ++w) n += __popc(bm[w]);
+    scan[tid] = (unsigned)n;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < SETS_THREADS; ++i) { const unsigned v = scan[i]; scan[i] = run; run += v; }
+        scan[SETS_THREADS] = run;
+    }
+    __syncthreads();
+    int pos = (int)scan[tid];
+    for (int w = w0; w < w1; ++w)
+        for (unsigned bits = bm[w]; bits; bits &= bits - 1u, ++pos)
+            if (pos < cap) lists[(size_t)b * cap + pos] = lo + (w << 5) + (__ffs(bits) - 1);
+    if (tid == 0) counts[b] = (int)scan[SETS_THREADS];
 }
 
 // node.mu = initial estimate (gbp_ba.py:116,123); landmark records also carry their slot range

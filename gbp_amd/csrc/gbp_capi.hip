@@ -236,30 +236,58 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         if (const char *nb = getenv("GBP_FUSED_BLOCKS")) n_wg = std::max(1, std::min(n_wg, atoi(nb)));      // (experiment switch, as in fused_plan)
         const int cgmax = fused_max_cams();      // (host arithmetic on the LDS budget: gbp_fused_plan.hpp)
         // Camera WINDOWS.  Workgroup b of the fused sweep walks the tiles [b T / n, (b + 1) T / n) and needs table rows for the cameras
-        // of THOSE tiles only.  In a sequence -- landmarks numbered along the trajectory, each seen from neighbouring cameras -- that is
-        // a short interval [lo, hi] however many cameras the graph has: the table becomes [hi - lo + 1][27] per workgroup, more cameras
-        // than fit the LDS as a whole still run the fused sweep, and the tables written and reduced every sweep shrink from
-        // workgroups x cameras rows to the sum of the windows.  Taken when the whole table would not fit, or when the windows add up to
-        // less than half of it; GBP_WINDOWS=0 / 1: never / whenever they fit.
-        h->wg_cam_range.clear();
+        // of THOSE tiles only.  In a sequence -- landmarks numbered along the trajectory, each seen from neighbouring cameras, now and
+        // then from a place visited before -- that is a few dozen cameras however many the graph has: the table becomes [set][27] per
+        // workgroup (k_wg_cam_sets: the distinct cameras of its tiles; a 16-bit map over the interval they lie in turns a camera into
+        // its table row), more cameras than fit the LDS as a whole still run the fused sweep, and the tables written and reduced every
+        // sweep shrink from workgroups x cameras rows to the sum of the sets.  Taken when the whole table would not fit, or when the sets
+        // add up to at most 0.7 of it; GBP_WINDOWS=0 / 1: never / whenever they fit.
+        h->wg_win.clear(); h->wg_cams.clear();
         long long rows = (long long)n_wg * C;
-        int max_window = 0;
         if (T > 0 && C > 0 && !(h->flags & GBP_FLAG_NO_FUSED) && p.num_undamped != 0) {
             int2 *d_rng = nullptr;
+            int *d_lists = nullptr, *d_counts = nullptr;
+            const int cap = cgmax;
             CHK(scratch_alloc(h, scratch, &d_rng, (size_t)n_wg));
+            CHK(scratch_alloc(h, scratch, &d_lists, (size_t)n_wg * cap)); CHK(scratch_alloc(h, scratch, &d_counts, (size_t)n_wg));
             hipLaunchKernelGGL(k_wg_cam_range, dim3((n_wg + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, h->stream, d_tiles, d_lrow0, lptr, lm2ref,
                                h->d_ref_cam, T, n_wg, d_rng);
             HIPCHK(hipGetLastError());
             std::vector<int2> rng((size_t)n_wg);
             HIPCHK(hipMemcpyAsync(rng.data(), d_rng, sizeof(int2) * (size_t)n_wg, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            long long sum = 0;
-            for (const int2 &r : rng) { const int w = r.y >= r.x ? r.y - r.x + 1 : 0; sum += w; max_window = std::max(max_window, w); }
-            const char *e = getenv("GBP_WINDOWS");
-            const bool want = e ? atoi(e) != 0 : (C > cgmax || 2 * sum <= rows);
-            if (want && max_window <= cgmax) { h->wg_cam_range = std::move(rng); rows = sum; }
+            int max_width = 0;
+            for (const int2 &r : rng) max_width = std::max(max_width, r.y >= r.x ? r.y - r.x + 1 : 0);
+            const size_t bm_bytes = ((size_t)(max_width + 31) / 32 + SETS_THREADS + 1) * sizeof(unsigned);
+            if (bm_bytes <= 64 * 1024 && fused_shmem_windows(1, max_width) <= (size_t)LDS_BYTES) {      // (else: intervals no map of the sweep could cover)
+                hipLaunchKernelGGL(k_wg_cam_sets, dim3(n_wg), dim3(SETS_THREADS), bm_bytes, h->stream, d_tiles, d_lrow0, lptr, lm2ref, h->d_ref_cam, T, n_wg,
+                                   d_rng, cap, d_lists, d_counts);
+                HIPCHK(hipGetLastError());
+                std::vector<int> counts((size_t)n_wg);
+                HIPCHK(hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * (size_t)n_wg, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                long long sum = 0;
+                int max_set = 0;
+                for (int n : counts) { sum += n; max_set = std::max(max_set, n); }
+                const char *e = getenv("GBP_WINDOWS");
+                // (a 125k-factor share of the headline graph, 500 random cameras: sets 0.63 of the whole tables, 26.6 against 29.2 us per
+                //  sweep; a 250k share: 0.86, 36.6 against 34.4 -- tools/sparse_probe.sh)
+                const bool want = e ? atoi(e) != 0 : (C > cgmax || 10 * sum <= 7 * rows);
+                if (want && max_set <= cap && fused_shmem_windows(max_set, max_width) <= (size_t)LDS_BYTES) {
+                    std::vector<int> lists((size_t)n_wg * cap);
+                    HIPCHK(hipMemcpyAsync(lists.data(), d_lists, sizeof(int) * lists.size(), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                    h->wg_win.resize((size_t)n_wg); h->wg_cams.reserve((size_t)sum);
+                    for (int b = 0; b < n_wg; ++b) {
+                        const int n = counts[(size_t)b];
+                        h->wg_win[(size_t)b] = make_int4(n ? rng[(size_t)b].x : 0, n, (int)h->wg_cams.size(), n ? rng[(size_t)b].y - rng[(size_t)b].x + 1 : 0);
+                        h->wg_cams.insert(h->wg_cams.end(), lists.begin() + (size_t)b * cap, lists.begin() + (size_t)b * cap + n);
+                    }
+                    rows = sum;
+                }
+            }
         }
-        const bool windowed = !h->wg_cam_range.empty();
+        const bool windowed = !h->wg_win.empty();
         // Few factors per camera: the fused sweep writes (and its reduce reads back) one 224-byte table row per camera and WORKGROUP
         // whatever the graph's size, the staged form one 128-byte row per FACTOR.  Below ~0.75 factors per (workgroup, camera) the
         // staged sweep is the faster one -- 13k / 30k / 60k / 90k factors x 500 cameras: 18.6 / 20.5 / 24.2 / 29.1 against 26.3 /
@@ -272,10 +300,10 @@ static int build_graph(gbp_ba *h, const gbp_ba_desc_t *d, std::vector<void *> &s
         const bool sparse = (double)F < staged_below * (double)rows;      // (windows: the rows the tables really have)
         h->staged_auto = sparse && !(h->flags & (GBP_FLAG_FORCE_FUSED | GBP_FLAG_NO_FUSED));
         if (h->staged_auto) h->flags |= GBP_FLAG_NO_FUSED;
-        if (h->flags & GBP_FLAG_NO_FUSED) h->wg_cam_range.clear();
+        if (h->flags & GBP_FLAG_NO_FUSED) { h->wg_win.clear(); h->wg_cams.clear(); }
         general_sweep = (h->flags & GBP_FLAG_NO_FUSED) || p.num_undamped == 0 || (C > cgmax && !windowed);   // its staging buffer is streamed every sweep too
         const size_t need = (general_sweep ? std::max<size_t>(Fz, 1) * p.crow * sizeof(double) + (64 << 8) : 0) + S * (LIN_ROWS + MSG_ROWS + (p.num_undamped == 0 ? XTRA_ROW : 0) + (p.loss != 0 ? 1 : 0)) * sizeof(double) + S * sizeof(int)
-                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)std::max<long long>(rows, 1) * (TROW * sizeof(double) + sizeof(int)) + (size_t)n_wg * sizeof(int4) + (size_t)std::max(C, 1) * sizeof(int2) + 3 * 4096
+                          + (size_t)std::max(L, 1) * LREC * sizeof(double) + (size_t)std::max<long long>(rows, 1) * (TROW * sizeof(double) + 2 * sizeof(int)) + (size_t)n_wg * sizeof(int4) + (size_t)std::max(C, 1) * sizeof(int2) + 4 * 4096
                           + (size_t)std::max(C, 1) * (CAMREC + CBEL + 27 + 27 + 1) * sizeof(double) + (size_t)std::max(L, 1) * sizeof(double)
                           + 2 * (size_t)grid_for(S) * sizeof(double) + (size_t)RELIN_RING * RELIN_LANES * sizeof(int)
                           + (size_t)(n_wg + 1) * sizeof(int) + (h->pack_mode ? 2 * (size_t)std::max(T, 1) * PART_ROW * sizeof(double) : 0) + (64 << 12);

@@ -9,7 +9,7 @@
 #include <cmath>
 #include <thread>
 
-int gbp::plan_fused_sweep(gbp_ba *h, int n_cus) { return fused_plan(h->fused, h->p, h->stream, n_cus, h->wg_cam_range.data(), (int)h->wg_cam_range.size()); }
+int gbp::plan_fused_sweep(gbp_ba *h, int n_cus) { return fused_plan(h->fused, h->p, h->stream, n_cus, h->wg_win.data(), h->wg_cams.data(), (int)h->wg_win.size()); }
 int gbp::fused_max_cams_of_this_build() { return fused_max_cams(); }
 
 // ------------------------------------------------------------------------------ launches --

@@ -142,9 +142,9 @@ GBP_DEV void issue_streams(const Params &p, int t, int lane, TileStreams &s, int
 // the persistent loop, the late landmark beliefs, the addressing -- is shared with the fused sweep.  (Rounds 1-3 ran the general sweep
 // as one wave per tile, k_factor_tile: 107 us at 1M factors; that kernel now serves the stage-wise calls and the dense remainder.)
 constexpr int STAGED_WAVE_DOUBLES = WAVE_LDS_DOUBLES + WTILE * CSTAGE_PLAIN + WTILE / 2;      // messages | rows | cpos
-// WINDOWED: the workgroup's LDS table covers only the cameras [lo, hi] its own tiles meet (FusedArgs::win) -- sequences, where a landmark
+// WINDOWED: the workgroup's LDS table covers only the cameras its own tiles meet (FusedArgs::win, wgcams) -- sequences, where a landmark
 // is seen by neighbouring cameras and the landmarks are numbered along the trajectory: any number of cameras, tables that shrink with
-// the windows (fused_plan).
+// the windows (fused_plan).  A 16-bit map behind the control words turns (camera - lowest camera of the set) into the table row.
 template <int LOSS, int NWAVES, bool STAGED = false, bool PINNED = false, bool SINGLE = false, bool WINDOWED = false>      // PINNED: FusedArgs::pin is in force (graphs beyond the memory-side cache); SINGLE: see the accumulation
 __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a, const int4 *__restrict__ tiles)
 {
@@ -162,6 +162,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     if (WINDOWED) {
         const int4 w = a.win[blockIdx.x];
         cam_base = __builtin_amdgcn_readfirstlane(w.x); cam_count = __builtin_amdgcn_readfirstlane(w.y); row_off = __builtin_amdgcn_readfirstlane(w.z);
+        unsigned short *map = reinterpret_cast<unsigned short *>(ctl + 2);
+        for (int i = tid; i < cam_count; i += NWAVES * 64) map[a.wgcams[row_off + i] - cam_base] = (unsigned short)i;
     }
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
@@ -344,8 +346,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
-        const int cloc = cam - cam_base;
-        const bool mine = active && (unsigned)cloc < (unsigned)cam_count;
+        const int cloc = WINDOWED ? (active ? (int)reinterpret_cast<const unsigned short *>(ctl + 2)[cam - cam_base] : 0) : cam - cam_base;
+        const bool mine = active && (WINDOWED || (unsigned)cloc < (unsigned)cam_count);
         // Lanes of a tile that hit the same camera add in rank (= lane) order.  Few of them: one round per rank, one lane per camera in
         // every ds_add_f64.  Many (graphs with a few dozen cameras: fr1desk has 63, and up to eight factors of a tile on one of them):
         // ALL lanes in one instruction -- the LDS atomic unit applies the lanes that share an address in ascending lane order, which IS
@@ -625,55 +627,57 @@ inline int single_probe(hipStream_t stream, int *mask)
 //  per sweep at C = 1000.  The general sweep's persistent STAGED form does the same graph in 127 us and has no camera limit: removed.)
 
 // Workgroup tile ranges + per-workgroup camera tables.
-// wg_range (n_range = workgroups, or 0): the workgroups' camera windows {lowest, highest camera of its tiles} -- build_graph's decision
-// (k_wg_cam_range); without them every workgroup's table covers all cameras.
-inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_cus, const int2 *wg_range = nullptr, int n_range = 0)
+// wg_win / wg_cams (n_win = workgroups, or 0): the workgroups' camera windows -- build_graph's decision (k_wg_cam_sets: per workgroup
+// {lowest camera, cameras in its set, offset into wg_cams, width of its interval}); without them every workgroup's table covers all cameras.
+inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_cus, const int4 *wg_win = nullptr, const int *wg_cams = nullptr, int n_win = 0)
 {
     if (p.F == 0 || p.C == 0 || p.T == 0) return 0;
     pl.n_blocks = std::max(1, std::min(p.T, n_cus));
     if (const char *nb = getenv("GBP_FUSED_BLOCKS")) pl.n_blocks = std::max(1, std::min(pl.n_blocks, atoi(nb)));   // experiment switch
-    pl.windowed = (wg_range && n_range == pl.n_blocks) ? 1 : 0;
+    pl.windowed = (wg_win && wg_cams && n_win == pl.n_blocks) ? 1 : 0;
     pl.rows_wave = 0;
     // the sweep's table shares the LDS with the waves' scratch: more cameras than fit run the general sweep (STAGED form of the same loop)
     const int cmax = fused_max_cams();
-    pl.max_window = 0;
+    pl.max_window = pl.max_width = 0;
     size_t table_rows = (size_t)pl.n_blocks * p.C;
-    std::vector<int4> win;
     std::vector<int2> cam_rows;
     std::vector<int> rowidx;
     if (pl.windowed) {
         // The rows of block_partials stay CAMERA-major -- the reduce reads one contiguous run per camera -- but a camera has rows only
-        // for the workgroups whose window holds it, in workgroup order.
-        win.resize((size_t)pl.n_blocks); cam_rows.assign((size_t)p.C, make_int2(0, 0));
-        std::vector<int> diff((size_t)p.C + 1, 0);
+        // for the workgroups whose set holds it, in workgroup order.
+        cam_rows.assign((size_t)p.C, make_int2(0, 0));
         table_rows = 0;
         for (int b = 0; b < pl.n_blocks; ++b) {
-            const int lo = wg_range[b].x, n = wg_range[b].y >= lo ? wg_range[b].y - lo + 1 : 0;
-            if (n && (lo < 0 || lo + n > p.C)) return -1;
-            win[(size_t)b] = make_int4(n ? lo : 0, n, (int)table_rows, 0);
-            if (n) { diff[(size_t)lo] += 1; diff[(size_t)lo + n] -= 1; }
-            table_rows += (size_t)n;
-            pl.max_window = std::max(pl.max_window, n);
+            const int4 w = wg_win[b];
+            if (w.y < 0 || w.z != (int)table_rows || (w.y && (w.x < 0 || w.x + w.w > p.C))) return -1;
+            for (int k = 0; k < w.y; ++k) {
+                const int c = wg_cams[(size_t)w.z + k];
+                if (c < w.x || c >= w.x + w.w) return -1;
+                cam_rows[(size_t)c].y++;
+            }
+            table_rows += (size_t)w.y;
+            pl.max_window = std::max(pl.max_window, w.y); pl.max_width = std::max(pl.max_width, w.w);
         }
-        if (table_rows > (size_t)INT32_MAX) return -1;
-        int run = 0, first = 0;
-        for (int c = 0; c < p.C; ++c) { run += diff[(size_t)c]; cam_rows[(size_t)c] = make_int2(first, 0); first += run; }
+        if (table_rows > (size_t)INT32_MAX || pl.max_width > 65536) return -1;
+        int first = 0;
+        for (int c = 0; c < p.C; ++c) { cam_rows[(size_t)c].x = first; first += cam_rows[(size_t)c].y; cam_rows[(size_t)c].y = 0; }
         rowidx.resize(std::max<size_t>(table_rows, 1));
         for (int b = 0; b < pl.n_blocks; ++b)
-            for (int k = 0; k < win[(size_t)b].y; ++k) {
-                int2 &cr = cam_rows[(size_t)win[(size_t)b].x + k];
-                rowidx[(size_t)win[(size_t)b].z + k] = cr.x + cr.y++;
+            for (int k = 0; k < wg_win[b].y; ++k) {
+                int2 &cr = cam_rows[(size_t)wg_cams[(size_t)wg_win[b].z + k]];
+                rowidx[(size_t)wg_win[b].z + k] = cr.x + cr.y++;
             }
         // few rows per camera ON AVERAGE: one wave adds them (k_cam_reduce_rows).  A wave takes 32 rows per round trip, so one camera
         // with many rows costs that launch microseconds where the tree form costs every camera a 1024-thread workgroup.
         const int wave_max = getenv("GBP_ROWS_WAVE_MAX") ? atoi(getenv("GBP_ROWS_WAVE_MAX")) : ROWS_WAVE_MAX;      // (tests: 0 keeps the tree form)
         pl.rows_wave = table_rows <= (size_t)wave_max * (size_t)p.C ? 1 : 0;
+        if (fused_shmem_windows(pl.max_window, pl.max_width) > (size_t)LDS_BYTES) { pl.windowed = 0; return 0; }
     }
-    if ((pl.windowed ? pl.max_window : p.C) > cmax) { pl.windowed = 0; return 0; }
+    if (!pl.windowed && p.C > cmax) return 0;
     pl.group_cams = pl.windowed ? std::max(pl.max_window, 1) : p.C;
     pl.n_groups = 1;
     const int acc_doubles = pl.group_cams * 27;
-    const size_t shmem = fused_shmem(pl.group_cams);
+    const size_t shmem = pl.windowed ? fused_shmem_windows(pl.group_cams, pl.max_width) : fused_shmem(pl.group_cams);
     double *d_bp = nullptr;                                 // (workgroup b walks tiles [b T / n_blocks, (b + 1) T / n_blocks): computed in the kernels)
     pl.table_rows = (long long)table_rows;
     if (fused_upload<double>(pl, &d_bp, nullptr, table_rows * TROW, stream)) return -1;
@@ -681,10 +685,10 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
     pl.args.block_partials = d_bp; pl.args.acc_doubles = acc_doubles; pl.args.cam_base = 0; pl.args.cam_count = std::min(p.C, pl.group_cams);
     pl.d_cam_rows = nullptr;
     if (pl.windowed) {
-        int4 *d_win = nullptr; int *d_rowidx = nullptr; int2 *d_cam_rows = nullptr;
-        if (fused_upload<int4>(pl, &d_win, win.data(), win.size(), stream) || fused_upload<int>(pl, &d_rowidx, rowidx.data(), rowidx.size(), stream) ||
-            fused_upload<int2>(pl, &d_cam_rows, cam_rows.data(), cam_rows.size(), stream)) return -1;
-        pl.args.win = d_win; pl.args.rowidx = d_rowidx; pl.d_cam_rows = d_cam_rows;
+        int4 *d_win = nullptr; int *d_rowidx = nullptr, *d_wgcams = nullptr; int2 *d_cam_rows = nullptr;
+        if (fused_upload<int4>(pl, &d_win, wg_win, (size_t)n_win, stream) || fused_upload<int>(pl, &d_rowidx, rowidx.data(), rowidx.size(), stream) ||
+            fused_upload<int>(pl, &d_wgcams, wg_cams, table_rows, stream) || fused_upload<int2>(pl, &d_cam_rows, cam_rows.data(), cam_rows.size(), stream)) return -1;
+        pl.args.win = d_win; pl.args.rowidx = d_rowidx; pl.args.wgcams = d_wgcams; pl.d_cam_rows = d_cam_rows;
     }
 #if defined(GBP_FUSED_DBG_SWITCHES) || defined(GBP_PHASE_TIMING)
     if (instrument_plan(pl, stream)) return -1;             // experimental/gbp_instrument.hpp: GBP_FUSED_DBG, the phase buffer

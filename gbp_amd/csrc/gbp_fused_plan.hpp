@@ -43,7 +43,7 @@ constexpr int NPHASE = 12;          // marks of the phase profile (experimental/
 
 struct FusedArgs {
     double *block_partials;     // [C][n_blocks][TROW]: 27 sums + one pad double, so that a row starts on 16 bytes (WINDOWED: the rows of a
-                                // camera are those of the workgroups whose camera window holds it, in workgroup order: FusedPlan::d_cam_rows)
+                                // camera are those of the workgroups whose camera set holds it, in workgroup order: FusedPlan::d_cam_rows)
     int acc_doubles;            // cameras of the group * 27
     int cam_base, cam_count;    // the cameras whose messages THIS launch adds up in its LDS table (all of them when C fits)
     int reverse;                // walk the workgroup's tile range backwards (every other sweep: see fused_launch)
@@ -54,8 +54,9 @@ struct FusedArgs {
                                 // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
     int pin;                    // the first `pin` tiles of every workgroup's range use the memory-side cache as `nt` says; the rest stream
                                 // PAST it altogether, loads and message stores (fused_plan: graphs beyond the cache size)
-    const int4 *win;            // WINDOWED: per workgroup {first camera of its table, cameras in it, offset into rowidx, -}, else NULL
-    const int *rowidx;          // WINDOWED: rowidx[offset + k] = the row of block_partials workgroup b's local camera k is written to
+    const int4 *win;            // WINDOWED: per workgroup {lowest camera, cameras in its set, offset into wgcams / rowidx, -}, else NULL
+    const int *wgcams;          // WINDOWED: wgcams[offset + k] = the k-th camera of the workgroup's set (ascending): its table row k
+    const int *rowidx;          // WINDOWED: rowidx[offset + k] = the row of block_partials that table row is written to
     int full_rows;              // STAGED: write whole camera-message rows (the staged x0 halves cannot be trusted: first staged sweep after
                                 // create / restore / a sweep of another kind); else only tiles in which a factor relinearised do
 };
@@ -66,7 +67,8 @@ struct FusedPlan {
     int n_blocks = 0;
     int xchg_blocks = 0;                             // grid of the merged reduce-exchange-finish launch (0: not asked yet)
     long long table_rows = 0;                        // rows of block_partials
-    int windowed = 0, max_window = 0;                // camera WINDOWS: every workgroup's table covers the cameras [lo, hi] its tiles meet (fused_plan)
+    int windowed = 0, max_window = 0, max_width = 0; // camera WINDOWS: every workgroup's table covers the cameras its own tiles meet (fused_plan): the largest
+                                                     // set, and the widest interval lowest .. highest camera (the 16-bit map camera -> table row covers it)
     int rows_wave = 0;                               // windowed and at most ROWS_WAVE_MAX rows per camera on average: the reduce runs one wave per camera
     const int2 *d_cam_rows = nullptr;                // windowed: per camera {first row, rows} of block_partials, else NULL (camera c: rows c n .. c n + n - 1)
     int single = 0;                                  // launch the SINGLE variant (all same-camera lanes of a tile in one ds_add_f64 per entry)
@@ -111,6 +113,9 @@ inline size_t fused_shmem(int C)
     const int acc_doubles = C * 27;
     return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * WAVE_LDS_DOUBLES + 1);
 }
+
+// camera windows: a table of `set` cameras, the per-wave scratch and the 16-bit map over an interval of `width` cameras
+inline size_t fused_shmem_windows(int set, int width) { return fused_shmem(std::max(set, 1)) + (((size_t)width * 2 + 7) & ~(size_t)7); }
 
 // most cameras whose table + the per-wave scratch fit the LDS (the plan falls back to the general sweep above it)
 inline int fused_max_cams()

@@ -62,7 +62,9 @@ struct gbp_ba {
     std::vector<void *> allocs;
     bool has_beliefs = false;
     int n_cus = 0;
-    std::vector<int2> wg_cam_range;              // per workgroup of the fused sweep: {lowest, highest} camera of its tiles (k_wg_cam_range); empty: no windows
+    std::vector<int4> wg_win;                    // camera windows, per workgroup of the fused sweep: {lowest camera, cameras in its set, offset into wg_cams, width of
+                                                 // the interval lowest .. highest}; empty: no windows (build_graph decides, fused_plan consumes)
+    std::vector<int> wg_cams;                    // the workgroups' camera sets, ascending, one after the other
     bool staged_auto = false;                    // the general sweep was picked by the sparseness rule (build_graph), not asked for
     int staged_xchg_blocks[3] = {0, 0, 0};       // grid cap of k_cam_staged_xchg<64 | 128 | 256> on this device (0: not asked yet)
     bool staged_attr_set = false;                // k_sweep_staged's dynamic-LDS attribute has been set on this handle's device (staged_launch)

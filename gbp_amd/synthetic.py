@@ -86,13 +86,14 @@ def _look_at_cameras(rng, n, target_jitter, r_lo, r_hi):
 
 def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK_K,
                    width=640.0, height=480.0, pix_noise=1.0, cam_t_noise=0.02,
-                   ball_radius=2.0, shell=(5.0, 6.0), target_jitter=0.2, min_depth=0.5, window=None):
+                   ball_radius=2.0, shell=(5.0, 6.0), target_jitter=0.2, min_depth=0.5, window=None, closures=0.0):
     """Generate a BA problem with exactly n_lmks*obs_per_lmk factors (camera-major order).
 
     window = w: a SEQUENCE instead of the headline graph's all-see-all -- every landmark is seen by obs_per_lmk cameras out of w
     consecutive ones, and the landmarks are numbered along the trajectory (by the centre of their window), the way a SLAM front end
     or an incremental reconstruction numbers them (the reference's fr1desk files: a landmark's cameras span 2 .. 46 consecutive
-    keyframes).  The default (None) is the graph of BASELINE configs 4-5 and draws exactly the random numbers it always drew."""
+    keyframes).  closures = p: that fraction of the landmarks is seen from anywhere along the trajectory instead (places visited
+    again).  The default (None) is the graph of BASELINE configs 4-5 and draws exactly the random numbers it always drew."""
     if obs_per_lmk > n_cams:
         raise ValueError("obs_per_lmk cannot exceed n_cams")
     rng = np.random.default_rng(seed)
@@ -134,7 +135,10 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
         vis = (z > min_depth) & (u >= 0) & (u < width) & (vv >= 0) & (vv < height)
         if window is not None:
             ctr = rng.uniform(window / 2.0, n_cams - window / 2.0, size=m)
-            vis &= np.abs(np.arange(n_cams)[None, :] + 0.5 - ctr[:, None]) <= window / 2.0
+            near = np.abs(np.arange(n_cams)[None, :] + 0.5 - ctr[:, None]) <= window / 2.0
+            if closures > 0.0:
+                near |= (rng.uniform(size=m) < closures)[:, None]
+            vis &= near
         keys = np.where(vis, rng.uniform(size=vis.shape), 2.0)
         pick = np.argpartition(keys, obs_per_lmk - 1, axis=1)[:, :obs_per_lmk]
         good = np.take_along_axis(keys, pick, axis=1).max(axis=1) < 1.5

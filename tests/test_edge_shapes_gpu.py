@@ -25,9 +25,10 @@ def run_pair(oracle_mod, prob, n_sweeps=14, **kw):
     return gap, o, e
 
 
-def test_camera_count_at_the_lds_boundary(oracle_mod):
+def test_camera_count_at_the_lds_boundary(oracle_mod, monkeypatch):
     from gbp_amd import _capi
     cmax = _capi.load().gbp_ba_fused_max_cams()
+    monkeypatch.setenv('GBP_WINDOWS', '0')         # whole tables (with camera windows these 90 one-tile workgroups need some 60 rows each: last block)
     assert 256 <= cmax <= 758                       # 160 KB / 216 B per camera, minus the per-wave scratch
     # one table in LDS (fused sweep) / one camera more: the general sweep, the same loop with camera-major staging.  (5 400 factors on
     # ~590 cameras are sparse: left to itself the library would run the staged sweep at every one of these sizes; fused=True asks for
@@ -40,13 +41,25 @@ def test_camera_count_at_the_lds_boundary(oracle_mod):
         assert gap < BELIEF_TOL, (C, gap)
         for a, b in zip(e.messages(), o.messages()):
             assert rel_err_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)) < 1e-5
+    monkeypatch.delenv('GBP_WINDOWS')
+    prob = make_synthetic(n_cams=2 * cmax, n_lmks=900, obs_per_lmk=6, seed=21)
+    gap, o, e = run_pair(oracle_mod, prob, n_sweeps=10, fused=True)
+    pi = e.plan_info()
+    assert pi['fused'] and 0 < pi['max_window'] <= 64 and gap < BELIEF_TOL, (pi, gap)      # random cameras, but one tile per workgroup: sets of at most 64
 
 
 def test_sparse_graphs_take_the_staged_sweep(oracle_mod, monkeypatch):
-    """Few factors per (workgroup, camera): the engine runs the staged sweep although the camera table would fit the LDS (one 128-byte row
-    per factor instead of one 224-byte table row per camera and workgroup); a dense graph keeps the fused sweep."""
+    """Few factors per (workgroup, camera).  Left alone the library runs the fused sweep with camera windows (each workgroup's table holds
+    the few dozen cameras of its own tile).  With whole tables only (GBP_WINDOWS=0) it runs the staged sweep although the camera table
+    would fit the LDS (one 128-byte row per factor instead of one 224-byte table row per camera and workgroup); a dense graph keeps
+    the fused sweep."""
     monkeypatch.delenv('GBP_STAGED_BELOW', raising=False)
     sparse = make_synthetic(n_cams=400, n_lmks=1500, obs_per_lmk=6, seed=4)          # 9 000 factors, 150 tiles x 400 cameras
+    monkeypatch.delenv('GBP_WINDOWS', raising=False)
+    gap, o, e = run_pair(oracle_mod, sparse, n_sweeps=12)
+    pi = e.plan_info()
+    assert pi['fused'] and 0 < pi['max_window'] <= 64 and pi['table_rows'] <= sparse.n_factors and not pi['staged_by_sparseness'] and gap < BELIEF_TOL, (pi, gap)
+    monkeypatch.setenv('GBP_WINDOWS', '0')
     gap, o, e = run_pair(oracle_mod, sparse, n_sweeps=12)
     assert e.info()['cam_groups'] == 0 and gap < BELIEF_TOL, (e.info(), gap)
     assert e.plan_info()['staged_by_sparseness'] is True
@@ -57,14 +70,16 @@ def test_sparse_graphs_take_the_staged_sweep(oracle_mod, monkeypatch):
     assert e.info()['cam_groups'] == 1 and gap < BELIEF_TOL, (e.info(), gap)
 
 
-@pytest.mark.parametrize('n_cams,window,obs,loss,single', [(2000, 12, 6, None, None), (2000, 12, 6, 'huber', '0'), (3000, 40, 10, 'constant', None),
-                                                          (1500, 64, 40, None, None), (300, 10, 5, None, None)])
-def test_camera_windows_of_a_sequence(oracle_mod, monkeypatch, n_cams, window, obs, loss, single):
+@pytest.mark.parametrize('n_cams,window,obs,loss,single,closures', [(2000, 12, 6, None, None, 0.0), (2000, 12, 6, 'huber', '0', 0.0), (3000, 40, 10, 'constant', None, 0.0),
+                                                                   (1500, 64, 40, None, None, 0.0), (300, 10, 5, None, None, 0.0),
+                                                                   (2000, 12, 6, None, None, 0.03), (5000, 30, 10, 'huber', None, 0.05)])
+def test_camera_windows_of_a_sequence(oracle_mod, monkeypatch, n_cams, window, obs, loss, single, closures):
     """A sequence: every landmark is seen from `obs` of `window` consecutive cameras, landmarks numbered along the trajectory.  The cameras
     of a workgroup's tiles form a short interval, so the fused sweep runs with per-workgroup camera WINDOWS -- with thousands of cameras,
     far beyond what one LDS table holds -- and gives the oracle's beliefs, messages and relinearisation ages (both accumulation variants,
     the robust losses, the dense packing at 40 factors per landmark, and a graph whose whole table WOULD fit but whose windows are
-    much smaller)."""
+    much smaller).  closures: that share of the landmarks is seen from anywhere along the trajectory -- a workgroup's cameras then span
+    the whole range, its SET is still a few dozen (the table rows go through a map over the interval)."""
     from gbp_amd import _capi
     cmax = _capi.load().gbp_ba_fused_max_cams()
     monkeypatch.delenv('GBP_WINDOWS', raising=False)
@@ -73,14 +88,14 @@ def test_camera_windows_of_a_sequence(oracle_mod, monkeypatch, n_cams, window, o
     else:
         monkeypatch.setenv('GBP_ACC_SINGLE', single)
     n_lmks = 36_000 // obs
-    prob = make_synthetic(n_cams=n_cams, n_lmks=n_lmks, obs_per_lmk=obs, seed=5, window=window)
+    prob = make_synthetic(n_cams=n_cams, n_lmks=n_lmks, obs_per_lmk=obs, seed=5, window=window, closures=closures)
     kw = dict(loss=loss, Nstds=2.0) if loss else {}
     from gbp_amd.engine import BAEngine
     o = oracle_mod.OracleBA.from_problem(prob, threads=8, **kw)
     e = BAEngine.from_problem(prob, **kw)
     pi = e.plan_info()
     assert pi['fused'] and not pi['staged_by_sparseness'], pi
-    assert 0 < pi['max_window'] <= min(cmax, 3 * window + n_cams // 64), pi
+    assert 0 < pi['max_window'] <= min(cmax, 3 * window + n_cams // 64 + int(closures * 36_000 / 128)), pi
     assert pi['table_rows'] < pi['n_blocks'] * n_cams // 2, pi
     assert pi['single'] == (single != '0'), pi
     if obs == 40:
@@ -128,7 +143,7 @@ def test_camera_windows_switch_and_fallbacks(oracle_mod, monkeypatch):
     e.close()
     monkeypatch.delenv('GBP_ROWS_WAVE_MAX')
     monkeypatch.delenv('GBP_WINDOWS')
-    wide = make_synthetic(n_cams=2 * cmax, n_lmks=3000, obs_per_lmk=6, seed=9, window=cmax + 200)
+    wide = make_synthetic(n_cams=2 * cmax, n_lmks=40_000, obs_per_lmk=6, seed=9, window=cmax + 200)      # (940 factors per workgroup on ~790 cameras)
     gap, o, e = run_pair(oracle_mod, wide, n_sweeps=8)
     assert not e.plan_info()['fused'] and e.plan_info()['max_window'] == 0 and gap < BELIEF_TOL, (e.plan_info(), gap)
     e.close()

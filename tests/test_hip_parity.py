@@ -465,10 +465,16 @@ def test_full_size_properties_1m_factors(eng_mod):
     e3.close(); e1.close()
 
 
-def test_many_cameras_fall_back_to_the_general_sweep(eng_mod, oracle_mod):
-    """C = 700 and 3000 cameras: the camera table of the fused sweep (C x 27 doubles) no longer fits the LDS, so the engine runs the
-    general sweep (the persistent loop with camera-major staging + k_cam_partial_staged), whatever `fused` asks for; incl. one
-    landmark larger than a tile (its belief comes from k_lmk_belief_list)."""
+@pytest.mark.parametrize('windows', [False, True])
+def test_many_cameras_fall_back_to_the_general_sweep(eng_mod, oracle_mod, monkeypatch, windows):
+    """C = 700 and 3000 cameras: ONE camera table of the fused sweep (C x 27 doubles) no longer fits the LDS.  With whole tables only
+    (GBP_WINDOWS=0) the engine runs the general sweep (the persistent loop with camera-major staging + k_cam_partial_staged),
+    whatever `fused` asks for; left alone it runs the fused sweep with camera windows where the workgroups' camera sets fit (these
+    graphs: a tile or two per workgroup), and `fused=False` still means the general sweep.  Incl. one landmark larger than a tile."""
+    if windows:
+        monkeypatch.delenv('GBP_WINDOWS', raising=False)
+    else:
+        monkeypatch.setenv('GBP_WINDOWS', '0')
     big = make_synthetic(n_cams=700, n_lmks=1, obs_per_lmk=90, seed=8)
     q = make_synthetic(n_cams=700, n_lmks=900, obs_per_lmk=6, seed=9)
     prob = BAProblem(K=q.K, cam_means=q.cam_means, lmk_means=np.concatenate([big.lmk_means[:1], q.lmk_means]),
@@ -477,7 +483,7 @@ def test_many_cameras_fall_back_to_the_general_sweep(eng_mod, oracle_mod):
     big3 = make_synthetic(n_cams=3000, n_lmks=4000, obs_per_lmk=12, seed=10)      # 16 factors per camera
     for pr, fused in ((prob, True), (prob, False), (big3, True)):
         gap, o, e = oracle_vs_engine(eng_mod, oracle_mod, pr, 20, fused)
-        assert e.info()['cam_groups'] == 0
+        assert e.info()['cam_groups'] == (1 if windows and fused else 0), e.plan_info()
         assert gap < BELIEF_TOL, gap
         assert np.array_equal(o.relin_state()['iters_since_relin'], e.relin_state()['iters_since_relin'])
         for a, b in zip(e.messages(), o.messages()):

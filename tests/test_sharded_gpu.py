@@ -173,11 +173,18 @@ def test_sharded_engine_synthetic_two_ranks(oracle_mod):
         assert rel_err_rows(le, rle[a:b]) < 1e-6 and rel_err_rows(ll, rll[a:b]) < 1e-6
 
 
-def test_sharded_engine_with_camera_groups_and_oversized_landmarks(oracle_mod):
-    """700 cameras (more than the fused sweep's LDS table holds: the general sweep) and landmarks seen by more than 64 cameras (chunk tiles whose
-    beliefs run on the side stream beside the exchange) through the in-library loop at world size 2."""
+@pytest.mark.parametrize('windows', [False, True])
+def test_sharded_engine_with_camera_groups_and_oversized_landmarks(oracle_mod, monkeypatch, windows):
+    """700 cameras (more than ONE LDS table of the fused sweep holds) and landmarks seen by more than 64 cameras (chunk tiles whose
+    beliefs run on the side stream beside the exchange) through the in-library loop at world size 2: on the general sweep
+    (GBP_WINDOWS=0), and the way the library runs it left alone -- the fused sweep with camera windows (one or two tiles per workgroup:
+    a few dozen of the 700 cameras each)."""
     from gbp_amd.engine import BAEngine
     from gbp_amd.synthetic import BAProblem
+    if windows:
+        monkeypatch.delenv('GBP_WINDOWS', raising=False)
+    else:
+        monkeypatch.setenv('GBP_WINDOWS', '0')
     big = make_synthetic(n_cams=700, n_lmks=3, obs_per_lmk=90, seed=8)
     q = make_synthetic(n_cams=700, n_lmks=1200, obs_per_lmk=6, seed=9)
     # the over-sized landmarks go to both ends so that each rank owns some
@@ -187,7 +194,7 @@ def test_sharded_engine_with_camera_groups_and_oversized_landmarks(oracle_mod):
     meas = np.concatenate([big.meas[big.lmk_idx < 2], q.meas, big.meas[big.lmk_idx == 2]])
     p = BAProblem(K=q.K, cam_means=q.cam_means, lmk_means=lm, meas=meas, cam_idx=cidx.astype(np.int32), lmk_idx=lidx.astype(np.int32))
     ref = BAEngine.from_problem(p)
-    assert ref.info()['cam_groups'] == 0
+    assert ref.info()['cam_groups'] == (1 if windows else 0) and (ref.plan_info()['max_window'] > 0) == windows, ref.plan_info()
     ref.generate_priors_var(50.0); ref.update_all_beliefs()
     ares, energies = oracle_mod.replay_ba(ref, 10, diagnostics=True)
     rce, rcl, rle, rll = ref.beliefs()
