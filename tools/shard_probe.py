@@ -15,14 +15,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--sizes', type=int, nargs='*', default=[50_000, 25_000, 12_500])
 ap.add_argument('--reps', type=int, default=400)
 ap.add_argument('--out', default='gpurun_out/shard_probe.json')
-ap.add_argument('--modes', nargs='*', default=['engine', 'general', 'peer1'])
+ap.add_argument('--modes', nargs='*', default=['engine', 'engine_whole', 'general', 'peer1', 'peer1_whole'])      # _whole: whole camera tables (GBP_WINDOWS=0)
 args = ap.parse_args()
 rows = []
 for n_l in args.sizes:
     p = make_synthetic(n_cams=500, n_lmks=n_l, obs_per_lmk=10, seed=0)
     for mode in args.modes:
+        os.environ.pop('GBP_WINDOWS', None)
+        if mode.endswith('_whole'):
+            os.environ['GBP_WINDOWS'] = '0'
         e = BAEngine.from_problem(p, fused=(mode not in ('general', 'peer1g')))
-        if mode in ('peer1', 'peer1g'):              # peer1g: the general sweep under the exchange (k_sweep_staged + k_cam_staged_xchg)
+        if mode in ('peer1', 'peer1g', 'peer1_whole'):              # peer1g: the general sweep under the exchange (k_sweep_staged + k_cam_staged_xchg)
             e.peer_connect(0, [e.peer_export(1)])
             it, upd = e.iterate_sharded, e.update_beliefs_sharded
         else:
@@ -39,8 +42,10 @@ for n_l in args.sizes:
             best.append(sorted(ts)[len(ts) // 2])
         us = min(best) * 1e6
         info = e.info()
-        rows.append(dict(n_lmks=n_l, n_factors=p.n_factors, mode=mode, us_per_sweep=us, n_blocks=info['n_blocks'], n_tiles=info['n_tiles']))
-        print(f"F={p.n_factors:8d} {mode:8s}: {us:7.1f} us/sweep  (workgroups {info['n_blocks']}, tiles {info['n_tiles']})", flush=True)
+        pi = e.plan_info()
+        rows.append(dict(n_lmks=n_l, n_factors=p.n_factors, mode=mode, us_per_sweep=us, n_blocks=info['n_blocks'], n_tiles=info['n_tiles'],
+                         widest_camera_set=pi['max_window'], table_rows=pi['table_rows']))
+        print(f"F={p.n_factors:8d} {mode:12s}: {us:7.1f} us/sweep  (workgroups {info['n_blocks']}, tiles {info['n_tiles']}, table rows {pi['table_rows']}, widest set {pi['max_window']})", flush=True)
         e.close()
 os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
 json.dump(rows, open(args.out, 'w'), indent=1)
