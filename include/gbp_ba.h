@@ -241,8 +241,8 @@ int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_b
  * inside one 64-slot tile, 1 the same with the landmarks above 64 factors cut into chunk tiles, 2 dense (tile t = factors [64 t, 64 t + 64)
  * of the landmark-major list: chosen when whole landmarks would leave more than 15 % of the slots empty and every landmark has at
  * least three factors).  From 1 on some landmarks span tiles: their beliefs are formed by a small kernel after the sweep; [8] camera
- * windows: the widest per-workgroup camera table of the fused sweep (each workgroup's table covers only the interval of cameras its own
- * tiles meet: sequences, where that interval is short however many cameras there are), 0 = every table covers all cameras; [9] rows
+ * windows: the largest per-workgroup camera table of the fused sweep (each workgroup's table covers only the distinct cameras its own
+ * tiles meet: sequences and sparse graphs, where those are few however many cameras there are), 0 = every table covers all cameras; [9] rows
  * of all tables together (windows: their sum; else workgroups x cameras), 0 under the general sweep. */
 #define GBP_PLAN_INFO_FIELDS 10
 int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n);
