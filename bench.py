@@ -628,7 +628,7 @@ def main(shard_factory=None, script=None):
                 "survey_equivalent_bytes": survey_bytes(F_local, L_local, C),
                 "survey_equivalent_gbs": survey_bytes(F_local, L_local, C) / (k_steady * 1e-3) / 1e9 if k_steady else 0.0}
         if red_ms is not None:
-            roof["reduce_kernel"] = "k_cam_reduce_rows" if plan.get('max_window') else "k_cam_reduce_tree"      # (windows with more than 64 rows on one camera keep the tree form)
+            roof["reduce_kernel"] = "k_cam_reduce_rows" if plan.get('reduce_by_wave') else "k_cam_reduce_tree"
             roof["reduce_avg_ms"] = red_ms
             roof["step_ms_device"] = mean_ms(pic['step'])
             # a kernel cannot take longer than the step that contains it

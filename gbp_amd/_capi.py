@@ -18,7 +18,7 @@ ABI_VERSION = 3
 FLAG_NO_FUSED = 1
 FLAG_DEVICE_INPUT = 2
 FLAG_FORCE_FUSED = 4
-PLAN_INFO_FIELDS = 10
+PLAN_INFO_FIELDS = 11
 CAM_PARTIAL_DOUBLES = 27
 COMM_ID_BYTES = 128
 XCH_ALWAYS = 1

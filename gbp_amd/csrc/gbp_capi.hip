@@ -607,7 +607,8 @@ int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n)
         h->fused.enabled ? 1 : 0, h->staged_auto ? 1 : 0, h->fused.enabled ? h->fused.single : 0, h->fused.single_probe,
         pinned ? h->fused.args.pin : -1, h->fused.enabled ? h->fused.n_blocks : std::max(1, std::min(h->p.T, h->n_cus)), h->p.T,
         h->pack_mode, h->fused.enabled && h->fused.windowed ? h->fused.max_window : 0,
-        h->fused.enabled ? (int32_t)std::min<long long>(h->fused.windowed ? h->fused.table_rows : (long long)h->fused.n_blocks * h->p.C, INT32_MAX) : 0};
+        h->fused.enabled ? (int32_t)std::min<long long>(h->fused.windowed ? h->fused.table_rows : (long long)h->fused.n_blocks * h->p.C, INT32_MAX) : 0,
+        h->fused.enabled && h->fused.windowed ? h->fused.rows_wave : 0};
     for (int i = 0; i < n && i < GBP_PLAN_INFO_FIELDS; ++i) out[i] = v[i];
     return GBP_OK;
 }

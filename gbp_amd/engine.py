@@ -417,4 +417,4 @@ class BAEngine:
         v = np.zeros(_capi.PLAN_INFO_FIELDS, np.int32)
         check(self._lib.gbp_ba_plan_info(self._h, iptr(v), v.size))
         return dict(fused=bool(v[0]), staged_by_sparseness=bool(v[1]), single=bool(v[2]), single_probe=int(v[3]), pinned_tiles=int(v[4]),
-                    n_blocks=int(v[5]), n_tiles=int(v[6]), pack_mode=int(v[7]), max_window=int(v[8]), table_rows=int(v[9]))
+                    n_blocks=int(v[5]), n_tiles=int(v[6]), pack_mode=int(v[7]), max_window=int(v[8]), table_rows=int(v[9]), reduce_by_wave=bool(v[10]))

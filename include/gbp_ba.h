@@ -243,8 +243,9 @@ int gbp_ba_info(gbp_ba_t *h, int32_t *fused_path, int32_t *n_tiles, int32_t *n_b
  * least three factors).  From 1 on some landmarks span tiles: their beliefs are formed by a small kernel after the sweep; [8] camera
  * windows: the largest per-workgroup camera table of the fused sweep (each workgroup's table covers only the distinct cameras its own
  * tiles meet: sequences and sparse graphs, where those are few however many cameras there are), 0 = every table covers all cameras; [9] rows
- * of all tables together (windows: their sum; else workgroups x cameras), 0 under the general sweep. */
-#define GBP_PLAN_INFO_FIELDS 10
+ * of all tables together (windows: their sum; else workgroups x cameras), 0 under the general sweep; [10] the reduce behind camera
+ * windows adds a camera's rows with one wave (1: at most 16 rows per camera on average) or as a tree (0: also without windows). */
+#define GBP_PLAN_INFO_FIELDS 11
 int gbp_ba_plan_info(gbp_ba_t *h, int32_t *out, int32_t n);
 int gbp_ba_phase_profile(gbp_ba_t *h, uint64_t *out, int32_t cap_rows, int32_t *n_rows, int32_t *n_cols);   /* debug builds with -DGBP_PHASE_TIMING only (tools/phase_profile.py): per-wave time per phase of the last fused sweep */
 int gbp_ba_check_layout(gbp_ba_t *h, int32_t *bad_slots);   /* debug: slots whose (camera, landmark) do not match the reference factor they hold (0 = sound) */
