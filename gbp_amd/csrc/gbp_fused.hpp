@@ -462,7 +462,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
     }
 }
 
-// Camera windows leave a camera a handful of rows (those of the workgroups whose window holds it: two to five in a sequence, where
+// Camera windows leave a camera a handful of rows (those of the workgroups whose camera set holds it: two to five in a sequence, where
 // k_cam_reduce_tree's 1024 threads per camera took 43.7 us for 10 000 cameras): one WAVE per camera.  Lane (g, pair) = (lane / 14,
 // lane % 14), g < 4, adds the 16-byte piece `pair` of rows g, g + 4, ...; the four partial sums are added in the order of g.  Returns
 // entry `lane` (< 27) of the sum.  fused_plan picks this form when the cameras have at most ROWS_WAVE_MAX rows on average (fr1desk_small

@@ -54,7 +54,7 @@ struct FusedArgs {
                                 // event's barrier packet (~5-8 us) and serialise the stream; this does neither.
     int pin;                    // the first `pin` tiles of every workgroup's range use the memory-side cache as `nt` says; the rest stream
                                 // PAST it altogether, loads and message stores (fused_plan: graphs beyond the cache size)
-    const int4 *win;            // WINDOWED: per workgroup {lowest camera, cameras in its set, offset into wgcams / rowidx, -}, else NULL
+    const int4 *win;            // WINDOWED: per workgroup {lowest camera, cameras in its set, offset into wgcams / rowidx, width of the interval the set lies in}, else NULL
     const int *wgcams;          // WINDOWED: wgcams[offset + k] = the k-th camera of the workgroup's set (ascending): its table row k
     const int *rowidx;          // WINDOWED: rowidx[offset + k] = the row of block_partials that table row is written to
     int full_rows;              // STAGED: write whole camera-message rows (the staged x0 halves cannot be trusted: first staged sweep after
