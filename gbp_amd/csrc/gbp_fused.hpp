@@ -727,9 +727,11 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
         if (getenv("GBP_PLAN_DEBUG")) fprintf(stderr, "[gbp] fused plan: T %d blocks %d touched %.1f MiB keep %.1f MiB pin %d tiles per workgroup\n", p.T, pl.n_blocks, touched / MiB, keep_mib, pl.args.pin);
     }
     pl.shmem = shmem;
+    // (the attribute belongs to the FUNCTION, not to this plan: every handle asks for the whole LDS, so that a later handle with a smaller
+    //  table cannot lower what an earlier one launches with)
 #define GBP_SET_SHMEM(K)                                                                                              \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
-                            (int)shmem) != hipSuccess) return -1;
+                            (int)LDS_BYTES) != hipSuccess) return -1;
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true>))
     GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true>))

@@ -163,6 +163,28 @@ def test_camera_windows_switch_and_fallbacks(oracle_mod, monkeypatch):
     e.close()
 
 
+def test_handles_with_different_tables_stay_launchable(oracle_mod):
+    """The dynamic-LDS attribute of the sweep kernels belongs to the function, not to a handle: a handle with a 500-camera table (145 KB of
+    LDS) keeps sweeping after handles with a 12-camera table and with camera windows were created in the same process, and all three
+    give the oracle's beliefs."""
+    from gbp_amd.engine import BAEngine
+    probs = [make_synthetic(n_cams=500, n_lmks=20_000, obs_per_lmk=10, seed=1), make_synthetic(n_cams=12, n_lmks=2000, obs_per_lmk=6, seed=2),
+             make_synthetic(n_cams=2000, n_lmks=6000, obs_per_lmk=6, seed=3, window=12)]
+    engines = []
+    for p in probs:                                  # (each handle sweeps once before the next one is created)
+        e = BAEngine.from_problem(p)
+        e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(2); e.sync()
+        engines.append(e)
+    assert [e.plan_info()['max_window'] > 0 for e in engines] == [False, False, True]
+    for e in engines:
+        e.iterate(4)
+    for p, e in zip(probs, engines):
+        o = oracle_mod.OracleBA.from_problem(p, threads=8)
+        o.generate_priors_var(50.0); o.update_all_beliefs(); o.iterate(6)
+        assert max(rel_err_rows(a, b) for a, b in zip(e.beliefs(), o.beliefs())) < BELIEF_TOL
+        e.close()
+
+
 def test_tiles_past_the_memory_side_cache_change_nothing(monkeypatch):
     """Graphs beyond the 256 MiB memory-side cache run the pinned variant of the fused sweep (FusedArgs::pin: the first tiles of a
     workgroup keep using the cache, the rest stream past it with nontemporal loads and stores).  Cache hints only: forced on a
