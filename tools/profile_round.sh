@@ -36,5 +36,11 @@ for dbg in 0 1 4 5 8 12 14; do
 done
 rm -f "$ROOT/tools/libgbp_dbg.so"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_general -o run -- $B --steps 100 --warmup 10 --no-fused > $OUT/bench_stats_general.log 2>&1
+python tools/summarize_round.py $OUT $TAG
+# bench.py reports `traffic` only from a profiles/<tag>_hbm_traffic.json that names the library it runs: put this call's counter passes
+# there first, then take the lines that are kept (the 1M run under rocprofv3 once more, the default command)
+cp $OUT/summary/${TAG}_hbm_traffic.json profiles/${TAG}_hbm_traffic.json
+rm -rf $OUT/stats_1m
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats_1m -o run -- $B --steps 200 --warmup 20 > $OUT/bench_stats_1m.log 2>&1
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python tools/summarize_round.py $OUT $TAG
