@@ -412,7 +412,22 @@ def g15(ref):
         save(f'G15_floatimpl_40it_{tag}', bal=np.array(fname), **out)
 
 
-ALL = dict(G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14, G15=g15)
+def g16(ref):
+    """More cameras than one LDS table of the fused sweep holds, through the reference itself: a synthetic SEQUENCE of 700 cameras
+    (gbp_amd.synthetic.make_synthetic(window=12, closures=0.03, seed=18): 1 200 landmarks seen from 6 of 12 consecutive cameras, 3 % of them from
+    anywhere along the trajectory), written in the reference's file layout (tests/golden/data/synth_seq700.txt: the fixture's input)
+    and run by the reference's own create_ba_graph + ba.py schedule for 20 sweeps.  The engine takes this graph with per-workgroup
+    camera windows (and, asked to, with the general sweep): the only fixtures beyond 500 cameras."""
+    from gbp import gbp_ba
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, '..', '..')))
+    from gbp_amd.synthetic import make_synthetic, write_bal
+    path = os.path.join(HERE, 'data', 'synth_seq700.txt')
+    write_bal(make_synthetic(n_cams=700, n_lmks=1200, obs_per_lmk=6, seed=18, window=12, closures=0.03), path, header='synthetic sequence, 700 cameras')
+    _, out = replay(gbp_ba, path, 20, checkpoints=(4, 12, 20), factor_checkpoints=(20,))
+    save('G16_seq700_20it', **out)
+
+
+ALL = dict(G16=g16, G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14, G15=g15)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

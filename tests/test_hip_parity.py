@@ -102,6 +102,34 @@ def test_g4_trace_vsmall(eng_mod, oracle_mod, fused):
         assert np.array_equal(s['st']['eta_damping'], g[f'it{k}_eta_damping'])
 
 
+@pytest.mark.parametrize('mode', ['windows', 'general', 'general_asked'])
+def test_g16_sequence_of_700_cameras_against_the_reference(eng_mod, oracle_mod, monkeypatch, mode):
+    """Fixture G16: the REFERENCE's own 20 sweeps (ba.py schedule) of a synthetic sequence with 700 cameras -- more than one LDS table of
+    the fused sweep holds.  Left alone the engine runs it as the fused sweep with per-workgroup camera windows; with whole tables only
+    (GBP_WINDOWS=0) or asked to (fused=False) as the general sweep.  All three: the reference's relinearisation counts, ARE / energy
+    traces, beliefs after 4 / 12 / 20 sweeps, messages and per-factor state after 20."""
+    g = golden('G16_seq700_20it')
+    if mode == 'general':
+        monkeypatch.setenv('GBP_WINDOWS', '0')
+    else:
+        monkeypatch.delenv('GBP_WINDOWS', raising=False)
+    _, e = make(eng_mod, 'synth_seq700.txt', fused=False if mode == 'general_asked' else None)
+    pi = e.plan_info()
+    assert pi['fused'] == (mode == 'windows') and (pi['max_window'] > 0) == (mode == 'windows'), pi
+    ares, energies, relin, snaps = replay_with_snaps(oracle_mod, e, 20, (4, 12, 20))
+    assert np.array_equal(relin, g['n_relin']) and relin.max() == 7200
+    assert np.allclose(ares, g['are'], rtol=1e-6) and np.allclose(energies, g['energy'], rtol=1e-5)
+    for k in (4, 12, 20):
+        gap = belief_gap(snaps[k]['bel'], g, f'it{k}_')
+        assert gap < BELIEF_TOL, (k, gap)
+    s = snaps[20]
+    for arr, name in zip(s['msg'], ('msg_cam_eta', 'msg_cam_lam', 'msg_lmk_eta', 'msg_lmk_lam')):
+        err = rel_err_rows(arr, g[f'it20_{name}'])
+        assert err < MSG_TOL, (name, err)
+    assert np.array_equal(s['st']['iters_since_relin'], g['it20_iters_since_relin'])
+    assert np.array_equal(s['st']['eta_damping'], g['it20_eta_damping'])
+
+
 @pytest.mark.parametrize('fused', [False, True])
 def test_g5_gate_small_config2(eng_mod, oracle_mod, fused):
     """BASELINE config 2 correctness gate: beliefs after 10 and 30 sweeps of fr1desk_small."""

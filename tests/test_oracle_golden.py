@@ -156,6 +156,20 @@ def test_g10_g11_other_data_files(oracle_mod):
     assert belief_gap(o.beliefs(), g, 'it6_') < 1e-6
 
 
+def test_g16_sequence_of_700_cameras(oracle_mod):
+    """The reference's 20 sweeps of a 700-camera synthetic sequence (tests/golden/data/synth_seq700.txt, written by make_golden.py from
+    gbp_amd.synthetic): the only fixture beyond 500 cameras -- the graph the engine runs with camera windows / the general sweep."""
+    g = golden('G16_seq700_20it')
+    _, o = make(oracle_mod, 'synth_seq700.txt', threads=8)
+    ares, energies, relin, snaps = replay_with_snaps(oracle_mod, o, 20, (4, 12, 20))
+    assert np.array_equal(relin, g['n_relin'])
+    assert np.allclose(ares, g['are'], rtol=1e-7) and np.allclose(energies, g['energy'], rtol=1e-6)
+    for k in (4, 12, 20):
+        assert belief_gap(snaps[k]['bel'], g, f'it{k}_') < 1e-6, k
+    assert np.array_equal(snaps[20]['st']['iters_since_relin'], g['it20_iters_since_relin'])
+    assert np.array_equal(snaps[20]['st']['eta_damping'], g['it20_eta_damping'])
+
+
 @pytest.mark.parametrize('loss', ['huber', 'constant'])
 def test_g7_robust_losses(oracle_mod, loss):
     g = golden('G7_robust_vsmall')
