@@ -668,9 +668,13 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
                 rowidx[(size_t)wg_win[b].z + k] = cr.x + cr.y++;
             }
         // few rows per camera ON AVERAGE: one wave adds them (k_cam_reduce_rows).  A wave takes 32 rows per round trip, so one camera
-        // with many rows costs that launch microseconds where the tree form costs every camera a 1024-thread workgroup.
-        const int wave_max = getenv("GBP_ROWS_WAVE_MAX") ? atoi(getenv("GBP_ROWS_WAVE_MAX")) : ROWS_WAVE_MAX;      // (tests: 0 keeps the tree form)
-        pl.rows_wave = table_rows <= (size_t)wave_max * (size_t)p.C ? 1 : 0;
+        // with many rows costs that launch microseconds where the tree form costs every camera a 1024-thread workgroup -- which is also
+        // why MANY cameras take the wave form whatever their rows (tools/manycam_probe.sh, random cameras, us per launch tree / wave:
+        // 2 000 cameras x 29 rows 11.4 / 6.8, x 56 rows 12.1 / 8.1; 5 000 x 24 24.8 / 9.6; 1 000 x 99 8.3 / 7.7; 500 x 100 5.4 / 6.5, x 160
+        // 5.9 / 7.7: tree ~ 2.6 + 0.004 C + 0.017 R, wave ~ 5.2 + 0.0003 C + 0.025 R with R in thousands of rows).
+        const char *e = getenv("GBP_ROWS_WAVE_MAX");        // (tests: 0 keeps the tree form)
+        const int wave_max = e ? atoi(e) : ROWS_WAVE_MAX;
+        pl.rows_wave = (table_rows <= (size_t)wave_max * (size_t)p.C || (!e && (double)p.C > 662.0 + 2.16e-3 * (double)table_rows)) ? 1 : 0;
         if (fused_shmem_windows(pl.max_window, pl.max_width) > (size_t)LDS_BYTES) { pl.windowed = 0; return 0; }
     }
     if (!pl.windowed && p.C > cmax) return 0;
