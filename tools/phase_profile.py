@@ -25,7 +25,11 @@ import numpy as np
 from gbp_amd import _capi
 from gbp_amd.engine import BAEngine
 from gbp_amd.synthetic import make_synthetic
-p = make_synthetic(n_cams=int(os.environ.get('CAMS', 500)), n_lmks=int(os.environ.get('LMKS', 100_000)), obs_per_lmk=int(os.environ.get('OBS', 10)), seed=0)
+if os.environ.get('BAL'):                      # a data file instead (BAL=tests/golden/data/fr1desk.txt)
+    from gbp_amd.balio import read_bal
+    p = read_bal(os.environ['BAL'])
+else:
+    p = make_synthetic(n_cams=int(os.environ.get('CAMS', 500)), n_lmks=int(os.environ.get('LMKS', 100_000)), obs_per_lmk=int(os.environ.get('OBS', 10)), seed=0)
 e = BAEngine.from_problem(p)
 e.generate_priors_var(50.0); e.update_all_beliefs(); e.iterate(60); e.sync()
 nr, nc = ct.c_int32(), ct.c_int32()
@@ -33,6 +37,8 @@ _capi.check(e._lib.gbp_ba_phase_profile(e._h, None, 0, ct.byref(nr), ct.byref(nc
 out = np.zeros((nr.value, nc.value), dtype=np.uint64)
 _capi.check(e._lib.gbp_ba_phase_profile(e._h, out.ctypes.data_as(ct.c_void_p), nr.value, ct.byref(nr), ct.byref(nc)))
 tot = out.sum(axis=1).astype(np.float64)
+busy = out[:, 6] > 0                            # waves that had a tile (small graphs: one wave per workgroup)
+print(f"waves with a tile: {int(busy.sum())} of {nr.value}; their ticks per phase (mean):", [int(x) for x in out[busy].astype(np.float64).mean(axis=0)])
 print(f"waves {nr.value}; ticks per wave: mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f} (s_memtime ticks)")
 share = out.astype(np.float64).sum(axis=0) / tot.sum()
 for n, s, m in zip(NAMES, share, out.astype(np.float64).mean(axis=0)):
