@@ -163,11 +163,12 @@ def test_camera_windows_switch_and_fallbacks(oracle_mod, monkeypatch):
     e.close()
 
 
-def test_handles_with_different_tables_stay_launchable(oracle_mod):
+def test_handles_with_different_tables_stay_launchable(oracle_mod, monkeypatch):
     """The dynamic-LDS attribute of the sweep kernels belongs to the function, not to a handle: a handle with a 500-camera table (145 KB of
     LDS) keeps sweeping after handles with a 12-camera table and with camera windows were created in the same process, and all three
     give the oracle's beliefs."""
     from gbp_amd.engine import BAEngine
+    monkeypatch.delenv('GBP_WINDOWS', raising=False)
     probs = [make_synthetic(n_cams=500, n_lmks=20_000, obs_per_lmk=10, seed=1), make_synthetic(n_cams=12, n_lmks=2000, obs_per_lmk=6, seed=2),
              make_synthetic(n_cams=2000, n_lmks=6000, obs_per_lmk=6, seed=3, window=12)]
     engines = []

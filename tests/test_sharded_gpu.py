@@ -363,6 +363,7 @@ def test_sharded_sequence_with_camera_windows(oracle_mod, monkeypatch, library_l
     than one LDS table holds), and the merged reduce-exchange-finish launch reads a camera's rows through the same per-camera row ranges.
     Against one engine on the whole graph."""
     from gbp_amd.engine import BAEngine
+    monkeypatch.delenv('GBP_WINDOWS', raising=False)
     if wave_rows:
         monkeypatch.delenv('GBP_ROWS_WAVE_MAX', raising=False)       # one wave per camera adds its few rows
     else:
