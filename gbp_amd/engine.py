@@ -33,9 +33,9 @@ class BAEngine:
     def __init__(self, K, cam_means, lmk_means, meas, cam_idx, lmk_idx, *, gauss_noise_std=2.0, loss=None,
                  Nstds=3.0, beta=0.01, num_undamped_iters=6, min_linear_iters=8, eta_damping=0.4,
                  device=0, fused=None, device_pointers=None):
-        """fused: None = the library picks the sweep (the fused one, unless the graph has more cameras than its LDS table holds or so few
-        factors per camera and workgroup that the staged general sweep is faster); True = the fused sweep whatever the sparseness rule
-        says (GBP_FLAG_FORCE_FUSED); False = the general sweep (GBP_FLAG_NO_FUSED).
+        """fused: None = the library picks the sweep (the fused one -- with per-workgroup camera windows where each workgroup's tiles meet
+        few of the cameras -- unless neither all cameras nor the workgroups' camera sets fit one LDS table; plan_info() says what it chose);
+        True = the fused sweep whatever the sparseness rule says (GBP_FLAG_FORCE_FUSED); False = the general sweep (GBP_FLAG_NO_FUSED).
         device_pointers = (C, L, F): the five arrays are then integer DEVICE addresses on `device` (float64 cam_means[C,6],
         lmk_means[L,3], meas[F,2]; int32 cam_idx[F], lmk_idx[F]) and nothing is uploaded (GBP_FLAG_DEVICE_INPUT)."""
         self._lib = _capi.load()
@@ -413,7 +413,8 @@ class BAEngine:
         return dict(fused=bool(a.value), cam_groups=a.value, n_tiles=b.value, n_blocks=c.value)
 
     def plan_info(self):
-        """What the sweep's plan decided (gbp_ba_plan_info): which sweep and why, the SINGLE accumulation variant and its probe."""
+        """What the sweep's plan decided (gbp_ba_plan_info): which sweep and why, the SINGLE accumulation variant and its probe, the tile
+        packing, camera windows (max_window = the largest per-workgroup camera set, 0: whole tables; table_rows; reduce_by_wave)."""
         v = np.zeros(_capi.PLAN_INFO_FIELDS, np.int32)
         check(self._lib.gbp_ba_plan_info(self._h, iptr(v), v.size))
         return dict(fused=bool(v[0]), staged_by_sparseness=bool(v[1]), single=bool(v[2]), single_probe=int(v[3]), pinned_tiles=int(v[4]),
