@@ -627,6 +627,32 @@ inline int single_probe(hipStream_t stream, int *mask)
 //  per sweep at C = 1000.  The general sweep's persistent STAGED form does the same graph in 127 us and has no camera limit: removed.)
 
 // Workgroup tile ranges + per-workgroup camera tables.
+// The fused sweep's variants -- loss x PINNED x SINGLE x WINDOWED (each a compile-time property of the persistent loop: a run-time
+// test per tile cost the headline 0.8-1.5 us per sweep) -- as one table, for the plan (LDS attribute) and the launch.
+using SweepKernel = void (*)(Params, FusedArgs, const int4 *);
+template <bool PINNED, bool SINGLE, bool WINDOWED>
+inline SweepKernel sweep_variant_of_loss(int loss)
+{
+    switch (loss) {
+    case 0: return k_sweep_wat<0, WAT_WAVES, false, PINNED, SINGLE, WINDOWED>;
+    case 1: return k_sweep_wat<1, WAT_WAVES, false, PINNED, SINGLE, WINDOWED>;
+    default: return k_sweep_wat<2, WAT_WAVES, false, PINNED, SINGLE, WINDOWED>;
+    }
+}
+inline SweepKernel sweep_variant(int loss, bool pinned, bool single, bool windowed)
+{
+    switch ((pinned ? 1 : 0) + (single ? 2 : 0) + (windowed ? 4 : 0)) {
+    case 0: return sweep_variant_of_loss<false, false, false>(loss);
+    case 1: return sweep_variant_of_loss<true, false, false>(loss);
+    case 2: return sweep_variant_of_loss<false, true, false>(loss);
+    case 3: return sweep_variant_of_loss<true, true, false>(loss);
+    case 4: return sweep_variant_of_loss<false, false, true>(loss);
+    case 5: return sweep_variant_of_loss<true, false, true>(loss);
+    case 6: return sweep_variant_of_loss<false, true, true>(loss);
+    default: return sweep_variant_of_loss<true, true, true>(loss);
+    }
+}
+
 // wg_win / wg_cams (n_win = workgroups, or 0): the workgroups' camera windows -- build_graph's decision (k_wg_cam_sets: per workgroup
 // {lowest camera, cameras in its set, offset into wg_cams, width of its interval}); without them every workgroup's table covers all cameras.
 inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_cus, const int4 *wg_win = nullptr, const int *wg_cams = nullptr, int n_win = 0)
@@ -733,20 +759,9 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
     pl.shmem = shmem;
     // (the attribute belongs to the FUNCTION, not to this plan: every handle asks for the whole LDS, so that a later handle with a smaller
     //  table cannot lower what an earlier one launches with)
-#define GBP_SET_SHMEM(K)                                                                                              \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize,           \
-                            (int)LDS_BYTES) != hipSuccess) return -1;
-    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES>))
-    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true>))
-    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true>))
-    GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, true>))
-    if (pl.windowed) {
-        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, false, true>))
-        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, false, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, false, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, false, true>))
-        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, false, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, false, true, true>))
-        GBP_SET_SHMEM((k_sweep_wat<0, WAT_WAVES, false, true, true, true>)) GBP_SET_SHMEM((k_sweep_wat<1, WAT_WAVES, false, true, true, true>)) GBP_SET_SHMEM((k_sweep_wat<2, WAT_WAVES, false, true, true, true>))
-    }
-#undef GBP_SET_SHMEM
+    for (int v = 0; v < 24; ++v)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_variant(v % 3, (v / 3) & 1, (v / 6) & 1, (v / 12) & 1)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return -1;
     pl.enabled = true;
     return 0;
 }
@@ -763,32 +778,7 @@ inline int fused_launch(FusedPlan &pl, const Params &p0, int robustify, int loca
     const dim3 grid(pl.n_blocks), block(WAT_WAVES * 64);
     if (e0) (void)hipEventRecord(e0, stream);
     const bool pinned = pl.args.pin != 0x7fffffff;
-    switch (p.loss + (pinned ? 4 : 0) + (pl.single ? 8 : 0) + (pl.windowed ? 16 : 0)) {
-    case 0: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 1: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 2: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 4: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 5: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 6: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 8: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 9: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 10: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 12: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 13: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 14: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 16: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 17: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 18: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 20: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 21: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 22: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, false, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 24: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 25: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 26: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, false, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 28: hipLaunchKernelGGL((k_sweep_wat<0, WAT_WAVES, false, true, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    case 29: hipLaunchKernelGGL((k_sweep_wat<1, WAT_WAVES, false, true, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    default: hipLaunchKernelGGL((k_sweep_wat<2, WAT_WAVES, false, true, true, true>), grid, block, pl.shmem, stream, p, pl.args, p.tiles); break;
-    }
+    hipLaunchKernelGGL(sweep_variant(p.loss, pinned, pl.single != 0, pl.windowed != 0), grid, block, pl.shmem, stream, p, pl.args, p.tiles);
     if (e1) (void)hipEventRecord(e1, stream);
     if (p.parts && !defer_big) hipLaunchKernelGGL(k_lmk_finish_parts, dim3((p.T + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, p);
     const size_t red_shmem = 0;                             // (static LDS)
