@@ -10,6 +10,7 @@ to the GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
 """
 from __future__ import annotations
 
+import fcntl
 import hashlib
 import os
 import shutil
@@ -66,12 +67,27 @@ def build(force=False, out=None, defines=(), extra_flags=(), capture=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
         log.append(r.stderr)
         return obj
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + [os.path.relpath(o, CSRC) for o in objs], cwd=CSRC,
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"linking {lib} failed:\n{r.stderr[-6000:]}")
+
+    # Two builds with the same flags share the object directory (xdist workers that both see needs_build(), a tool's scratch build beside
+    # the product's): one at a time, under a lock on the directory; and the library appears under its name only when it is complete
+    # (linked beside it, then os.replace): nobody can dlopen a half-written libgbp_hip.so.
+    with open(os.path.join(tmp, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and out is None and not needs_build():      # somebody else built it while this process waited
+            return (lib, '') if capture else lib
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        partial = f'{lib}.link{os.getpid()}.tmp'
+        try:
+            # (the output NAME is not recorded inside the library: the sha256 is that of a link straight to `lib`)
+            r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', partial] + [os.path.relpath(o, CSRC) for o in objs], cwd=CSRC,
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"linking {lib} failed:\n{r.stderr[-6000:]}")
+            os.replace(partial, lib)
+        finally:
+            if os.path.exists(partial):
+                os.remove(partial)
     return (lib, ''.join(log)) if capture else lib
 
 

@@ -255,23 +255,15 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
     po.n = n; po.seq = pe.seq;
     for (int r = 0; r < n; ++r) po.dst[r] = peer_data(h, pe.base[r], n, half, pe.rank);
     PeerWait w{peer_data(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1, nullptr};
-    const bool big = with_messages && h->p.parts != nullptr;
     // Without a rendezvous hook everything behind the fused sweep is ONE launch (k_cam_reduce_xchg); logical ranks on one device
     // (the hook is set) keep reduce / push and finish apart, with the hook between them, so that they never spin on each other.
     const bool merged = !h->xch_fn && with_messages && !getenv("GBP_PEER_SPLIT");      // (fused: k_cam_reduce_xchg; general: k_cam_staged_xchg)
     bool finished = false;
-    CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, &finished, big, &po, merged ? &w : nullptr));
-    if (big) {
-        if (!h->side_stream) {
-            HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-        CHK(launch_finish_parts(h, h->side_stream));
-        HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
-    }
+    // The beliefs of the landmarks that span tiles (k_lmk_finish_parts) go out on THIS stream, as a short launch between the sweep
+    // kernel and the reduce (1.3 us, EXPERIMENTS.md round 5).  Round 5 forked them onto a side stream "beside the exchange" -- but the
+    // fork event was recorded behind the merged reduce -> push -> wait -> finish launch, so they ran strictly after it, plus two event
+    // hops.  Here the exchange IS that one launch: there is nothing to run beside.
+    CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, &finished, false, &po, merged ? &w : nullptr));
     if (!finished) {
         if (h->xch_fn) {                                     // rendezvous hook (logical ranks on ONE device: tests)
             int rc = h->xch_fn(h->xch_ctx, nullptr, nullptr, 0, h->stream);
@@ -279,7 +271,6 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
         }
         CHK(launch_cam_finish(h, nullptr, n, 0, &w));
     }
-    if (big) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return GBP_OK;
 }
 
@@ -293,7 +284,9 @@ static int sharded_step(gbp_ba *h, int with_messages, int robustify, int local_r
         if (!finished) CHK(launch_cam_finish(h, h->d_partial, 1, 0));
         return GBP_OK;
     }
-    const bool big = with_messages && h->p.parts != nullptr;     // landmarks that span tiles: their beliefs need nothing from the exchange: side stream
+    // landmarks that span tiles: their beliefs need nothing from the exchange.  The side stream picks them up behind the reduce launch
+    // (the fork event follows it) and runs them while the exchange function -- an RCCL all-gather, a caller's MPI -- owns this stream.
+    const bool big = with_messages && h->p.parts != nullptr;
     CHK(sweep_begin(h, with_messages, robustify, local_relin, h->d_send, 0, nullptr, big));
     if (big) {
         if (!h->side_stream) {

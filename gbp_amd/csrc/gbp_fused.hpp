@@ -22,9 +22,10 @@
 //     (workgroup, tile, rank) -- independent of which wave ran which tile and of timing.  Within a rank round
 //     every lane targets a different camera, so the LDS ds_add_f64 is a plain read-modify-write.
 //
-// HBM traffic per sweep: F*(21 read + 10 written doubles + 12 B of indices) + L*(24 read + 12 written doubles)
-// + the workgroup tables (256 * C * 27 doubles written and read once) -- under a third of the "algorithmic"
-// 1072 B per factor of SURVEY.md 8d, which assumed dense messages and a second pass over them.
+// HBM traffic per sweep (bench.py layout_bytes): F*(21 read + 10 written doubles + 8 B of meta | state words)
+// + L*(a 20-double record read + 9 doubles of mean | covariance written) + the workgroup tables (256 * C rows of 28 doubles,
+// written here and read once by the reduce) -- under a third of the "algorithmic" 1072 B per factor of SURVEY.md 8d, which
+// assumed dense messages and a second pass over them.
 //
 // Tried and measured on MI355X, not kept (round 2): a software-pipelined loop that requests everything tile k+1 reads (streams,
 // landmark records, camera records) during the back half of tile k.  With no spills and the operands of every tile already on

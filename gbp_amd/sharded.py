@@ -19,6 +19,8 @@ logic over gloo with a test double for the engine; that path drives gbp_ba_shard
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .synthetic import BAProblem
@@ -81,6 +83,15 @@ class _HipShard:
         if exchange == 'callback':
             self.engine.set_exchange(lambda s, r, n, st: dist.device_exchange(rank, s, r, n, st), rank, world, always_exchange)
         elif exchange == 'peer':
+            # parsed HERE, outside the try blocks below: a malformed value is the caller's error and must not look like a failed self-test
+            # (which would quietly downgrade the job to RCCL: ADVICE r5)
+            raw = os.environ.get('GBP_PEER_SELFTEST_MS', '5000')
+            try:
+                selftest_ms = int(float(raw))
+            except ValueError:
+                raise ValueError(f"GBP_PEER_SELFTEST_MS={raw!r} is not a number of milliseconds") from None
+            if selftest_ms < 1:
+                raise ValueError(f"GBP_PEER_SELFTEST_MS={raw!r}: the peer self-test needs a positive time-out")
             if threads:                                      # logical ranks must not spin on each other: rendezvous hook between
                 self.engine.set_exchange(lambda s, r, n, st: dist.device_exchange(rank, s, r, n, st), rank, world, False)
             # every rank reaches every collective below whatever fails locally: a failure travels as data, then all ranks raise
@@ -104,7 +115,7 @@ class _HipShard:
                 # Before the first sweep: one tagged probe row from every rank to every rank, checked on arrival (gbp_ba_peer_selftest).
                 # A pair of devices whose peer mapping does not work shows up HERE, by name, and the caller falls back to RCCL.
                 try:
-                    self.engine.peer_selftest(int(float(__import__('os').environ.get('GBP_PEER_SELFTEST_MS', '5000'))))
+                    self.engine.peer_selftest(selftest_ms)
                     err = None
                 except Exception as e:                       # noqa: BLE001
                     err = f"error: {e}"

@@ -24,6 +24,8 @@ _dp, _ip = ct.POINTER(ct.c_double), ct.POINTER(ct.c_int)
 
 @pytest.fixture(scope='module')
 def hm():
+    if os.environ.get('GBP_HOSTMATH_SANITIZED_LIB'):          # tests/test_sanitizers.py: the same source under ASan + UBSan
+        return ct.CDLL(os.environ['GBP_HOSTMATH_SANITIZED_LIB'])
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     deps = [SRC] + [os.path.join(CSRC, f) for f in ('gbp_math.hpp', 'gbp_kernels.hpp')]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
