@@ -108,6 +108,8 @@ int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank
 int gbp_ba_comm_unique_id(void *id128, const char *rccl_path)
 {
     if (!id128) return fail(GBP_EINVAL, "null argument");
+    // (test switch: a node whose RCCL cannot come up -- the callers' fallbacks, ShardedBA and bench.py's line, are exercised with it)
+    if (getenv("GBP_RCCL_FAIL")) return fail(GBP_ESTATE, "RCCL switched off by GBP_RCCL_FAIL (test switch)");
     CHK(rccl_load(rccl_path));
     ncclUniqueId id;
     const ncclResult_t rc = g_rccl.GetUniqueId(&id);

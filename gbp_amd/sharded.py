@@ -166,16 +166,31 @@ class ShardedBA:
     """BAFactorGraph surface (gbp_ba.py:12-69) over `world` ranks; every rank calls every method."""
 
     def __init__(self, problem: BAProblem, device=0, fused=None, engine_factory=None, dist=None, library_loop=True,
-                 always_exchange=False, exchange='auto', **cfg):
+                 always_exchange=False, exchange='auto', local_shard=False, **cfg):
+        """local_shard: `problem` is THIS rank's shard already -- its landmarks (numbered from 0) with their factors, and the cameras all
+        ranks share -- the way a loader that reads one partition per rank, or a generator that makes every rank's landmarks on that
+        rank, hands them over; the global landmark numbering is rank order.  (Without it every rank holds the whole problem and cuts
+        its own range out of it: fine at 1M factors, 8 x 8M factors of host arrays and generator time at the sizes that fill 8 GPUs.)"""
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.C, self.F_total, self.L_total = problem.n_cams, problem.n_factors, problem.n_lmks
-        self.bounds = partition_landmarks(problem.lmk_idx, problem.n_lmks, self.world)
-        lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
-        self.lmk_range = (lo, hi)
-        local = local_problem(problem, lo, hi)
+        if local_shard:
+            sizes = [None] * self.world
+            dist.all_gather_object(sizes, (int(problem.n_lmks), int(problem.n_factors), int(problem.n_cams)))
+            if len({c for _, _, c in sizes}) != 1:
+                raise ValueError(f"local shards disagree on the number of cameras: {[c for _, _, c in sizes]}")
+            self.C, self.F_total, self.L_total = problem.n_cams, sum(f for _, f, _ in sizes), sum(l for l, _, _ in sizes)
+            self.bounds = np.concatenate([[0], np.cumsum([l for l, _, _ in sizes])]).astype(np.int64)
+            lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+            self.lmk_range = (lo, hi)
+            local = problem
+        else:
+            self.C, self.F_total, self.L_total = problem.n_cams, problem.n_factors, problem.n_lmks
+            self.bounds = partition_landmarks(problem.lmk_idx, problem.n_lmks, self.world)
+            lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+            self.lmk_range = (lo, hi)
+            local = local_problem(problem, lo, hi)
         factory = engine_factory or (lambda p: _HipShard(p, device, fused, **cfg))
         self.shard = factory(local)
         self.engine = self.shard.engine
@@ -241,6 +256,17 @@ class ShardedBA:
         return self.shard.stream_ctx() if hasattr(self.shard, 'stream_ctx') else contextlib.nullcontext()
 
     def _exchange(self):
+        side = getattr(self.shard, 'side_device', None)
+        if side is not None and side.type == 'cpu' and getattr(self._partial, 'is_cuda', False):
+            # a CPU side channel (gloo: ranks that share one GPU, or a node whose RCCL did not come up) under device buffers:
+            # the partial sums travel through the host
+            self.shard.sync()
+            host = self._partial.cpu()
+            out = host.new_empty(host.numel() * self.world)
+            self.dist.all_gather_into_tensor(out, host)
+            with self._ctx():
+                self._gathered.copy_(out)
+            return
         with self._ctx():
             self.dist.all_gather_into_tensor(self._gathered, self._partial)
 

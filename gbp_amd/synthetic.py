@@ -86,14 +86,17 @@ def _look_at_cameras(rng, n, target_jitter, r_lo, r_hi):
 
 def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK_K,
                    width=640.0, height=480.0, pix_noise=1.0, cam_t_noise=0.02,
-                   ball_radius=2.0, shell=(5.0, 6.0), target_jitter=0.2, min_depth=0.5, window=None, closures=0.0):
+                   ball_radius=2.0, shell=(5.0, 6.0), target_jitter=0.2, min_depth=0.5, window=None, closures=0.0, lmk_seed=None):
     """Generate a BA problem with exactly n_lmks*obs_per_lmk factors (camera-major order).
 
     window = w: a SEQUENCE instead of the headline graph's all-see-all -- every landmark is seen by obs_per_lmk cameras out of w
     consecutive ones, and the landmarks are numbered along the trajectory (by the centre of their window), the way a SLAM front end
     or an incremental reconstruction numbers them (the reference's fr1desk files: a landmark's cameras span 2 .. 46 consecutive
     keyframes).  closures = p: that fraction of the landmarks is seen from anywhere along the trajectory instead (places visited
-    again).  The default (None) is the graph of BASELINE configs 4-5 and draws exactly the random numbers it always drew."""
+    again).  The default (None) is the graph of BASELINE configs 4-5 and draws exactly the random numbers it always drew.
+    lmk_seed = k: the CAMERAS (poses and their initial estimates) are those of `seed`, whatever k; the landmarks, who sees them and the
+    pixel noise come from a generator of their own, (seed, k) -- so that every rank of a sharded job can make its own landmarks against
+    the cameras all ranks share (bench.py's secondary workload: ShardedBA(local_shard=True))."""
     if obs_per_lmk > n_cams:
         raise ValueError("obs_per_lmk cannot exceed n_cams")
     rng = np.random.default_rng(seed)
@@ -112,6 +115,10 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
     t_cw = np.concatenate(t_list)[:n_cams]
     w_cw = _log_so3(R_cw)
     R_cw = rodrigues(w_cw)  # the rotation the engine will actually reconstruct
+    t_init_shared = None
+    if lmk_seed is not None:
+        t_init_shared = t_cw + rng.normal(scale=cam_t_noise, size=t_cw.shape)      # the cameras' estimates must not depend on k
+        rng = np.random.default_rng([int(seed), int(lmk_seed)])
 
     # landmarks + visibility, chunked so that memory stays bounded at 100k x 500
     if window is not None and not obs_per_lmk <= window <= n_cams:
@@ -169,7 +176,7 @@ def make_synthetic(n_cams=500, n_lmks=100_000, obs_per_lmk=10, seed=0, K=FR1DESK
     meas = meas + rng.normal(scale=pix_noise, size=meas.shape)
 
     # initial estimates: noisy camera translations, exact rotations (data/fr1desk.txt:4-7)
-    t_init = t_cw + rng.normal(scale=cam_t_noise, size=t_cw.shape)
+    t_init = t_init_shared if t_init_shared is not None else t_cw + rng.normal(scale=cam_t_noise, size=t_cw.shape)
     cam_means = np.concatenate([t_init, w_cw], axis=1)
 
     # landmarks start on the ray of their first observation at the mean scene depth

@@ -16,6 +16,17 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 DATA = os.path.join(GOLDEN, 'data')
 
+# Fixture G15b = G15's run carried on to ba.py's default 200 sweeps.  What it shows is that `--float_implementation`
+# does not CONVERGE on these files in the reference itself: with the priors at 1 / 250 000 of the factors' information the reference's own
+# ARE turns around (fr1desk_small: 2.67 px at sweep 40, 8.6 at 50, 322 at 110, 20 558 at 140) and in sweep 143 np.linalg.inv raises
+# "Singular matrix" inside Factor.compute_messages (gbp.py:366) -- the reference does not survive its own schedule; on fr1desk_vsmall it
+# survives with the ARE at 1 159 px (1.3 at sweep 60).  A diverging trajectory is chaotic: two float64 implementations of the same
+# formulas stay together only while it is still contracting.  G15B_HOLD = per file (last checkpoint with beliefs within BASELINE's 1e-4,
+# last sweep with the relinearisation counts exact and the ARE within 1e-3); beyond it the gap is RECORDED, not bounded (the C oracle
+# -- the reference's dense arithmetic, another inverse routine -- leaves the reference at the same sweeps as the engine does).
+G15B_HOLD = {'vsmall': (75, 100), 'small': (40, 55)}
+G15B_NEAR = {'small': (50, 3e-4)}      # the first checkpoint past the gate: 1e-4 is crossed here or at the next one (oracle: 9.6e-5 / 1.2e-4 at 50 / 60)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")

@@ -412,6 +412,55 @@ def g15(ref):
         save(f'G15_floatimpl_40it_{tag}', bal=np.array(fname), **out)
 
 
+G15B_CHECKPOINTS = (12, 17, 26, 35, 40, 50, 60, 75, 100, 125, 150, 175, 200)
+
+
+def g15b(ref, which=('vsmall', 'small')):
+    """ba.py --float_implementation at ba.py's DEFAULT length (`--n_iters 200`, ba.py:13,38-44,62-65,86-88): G15's run carried on from
+    sweep 40 to sweep 200 (the one regime where the engine sits within a factor of two of BASELINE's 1e-4 had only 40
+    of its 200 sweeps pinned).  Beliefs and every factor's iters_since_relin after the sweeps of G15B_CHECKPOINTS; ARE / energy /
+    relinearisation counts every sweep."""
+    from gbp import gbp_ba
+    for tag in which:
+        fname = dict(vsmall='fr1desk_vsmall.txt', small='fr1desk_small.txt')[tag]
+        cfg = default_configs()
+        graph = gbp_ba.create_ba_graph(os.path.join(HERE, 'data', fname), cfg)
+        graph.generate_priors_var(weaker_factor=cfg['prior_std_weaker_factor'])
+        graph.update_all_beliefs()
+        weakening = np.log10(100.0) / 5
+        out, are, energy, relins, failed = {}, [], [], [], None
+        for i in range(200):
+            if (i + 1) % 2 == 0 and i < 10:
+                graph.weaken_priors(weakening)
+            if i == 3 or i == 8:
+                for f in graph.factors:
+                    f.iters_since_relin = 1
+            are.append(graph.are())
+            energy.append(graph.energy())
+            relins.append(sum(1 for f in graph.factors if f.iters_since_relin == 0))
+            try:
+                graph.synchronous_iteration(robustify=True, local_relin=True)
+            except np.linalg.LinAlgError as e:
+                # the REFERENCE does not survive its own schedule on this file: np.linalg.inv raises inside Factor.compute_messages
+                # (gbp.py:366).  What it produced up to here is the fixture; the sweep it died in and the error are recorded.
+                failed = (i, f'{type(e).__name__}: {e}')
+                print(f'[G15b:{tag}] the reference raised {failed[1]} in sweep {i + 1}')
+                break
+            k = i + 1
+            if k in G15B_CHECKPOINTS:
+                for name, arr in beliefs_of(graph).items():
+                    out[f'it{k}_{name}'] = arr
+                out[f'it{k}_iters_since_relin'] = np.array([f.iters_since_relin for f in graph.factors], dtype=np.int32)
+        if failed is None:
+            out['are_final'] = np.array(graph.are())
+            out['energy_final'] = np.array(graph.energy())
+        out['reference_failed_in_sweep'] = np.array(-1 if failed is None else failed[0] + 1)
+        out['reference_error'] = np.array('' if failed is None else failed[1])
+        out['lmk_degree'] = np.array([len(n.adj_factors) for n in graph.lmk_nodes], dtype=np.int32)
+        save(f'G15b_floatimpl_200it_{tag}', bal=np.array(fname), checkpoints=np.array(G15B_CHECKPOINTS),
+             are=np.array(are), energy=np.array(energy), n_relin=np.array(relins, dtype=np.int32), **out)
+
+
 def g16(ref):
     """More cameras than one LDS table of the fused sweep holds, through the reference itself: a synthetic SEQUENCE of 700 cameras
     (gbp_amd.synthetic.make_synthetic(window=12, closures=0.03, seed=18): 1 200 landmarks seen from 6 of 12 consecutive cameras, 3 % of them from
@@ -427,7 +476,7 @@ def g16(ref):
     save('G16_seq700_20it', **out)
 
 
-ALL = dict(G16=g16, G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14, G15=g15)
+ALL = dict(G16=g16, G1=g1, G1b=g1b, G2=g2_g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G12=g12, G13=g13, G14=g14, G15=g15, G15b=g15b)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA, belief_gap, golden
+from conftest import DATA, G15B_HOLD, G15B_NEAR, belief_gap, golden
 from gbp_amd.balio import read_bal
 
 pytestmark = pytest.mark.gpu
@@ -91,4 +91,41 @@ def test_g15_float_implementation_through_relinearisation(oracle_mod, tag, fused
     assert np.array_equal(np.array(relin[:40]), g['n_relin'])
     assert np.allclose(ares[:16], g['are'][:16], rtol=1e-6) and np.allclose(ares[:40], g['are'], rtol=G15_ARE_TOL)
     assert sorted(gaps) == list(checkpoints) and gaps[12] < 1e-6 and max(gaps.values()) < G15_BELIEF_TOL, gaps
+    e.close()
+
+
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'general'])
+@pytest.mark.parametrize('tag', ['vsmall', 'small'])
+def test_g15b_float_implementation_at_ba_default_length(oracle_mod, tag, fused):
+    """`ba.py --float_implementation` at ba.py's default length, against the reference's own run as far as it gets (fixture G15b; conftest
+    G15B_HOLD says what the run is: the REFERENCE diverges under this flag -- ARE 2.7 -> 20 558 px on fr1desk_small -- and dies of a
+    singular matrix in sweep 143).  Asserted while the trajectory is still contracting: beliefs within BASELINE's 1e-4 at every checkpoint
+    up to G15B_HOLD, every per-factor age equal there, relinearisation counts exact and the ARE within 1e-3 up to the hold sweep.  The gap
+    at the later checkpoints is printed (and recorded by tests/tools/g15b_trace.py into profiles/), not bounded: the oracle leaves the
+    reference at the same sweeps."""
+    from gbp_amd.engine import BAEngine
+    g = golden(f'G15b_floatimpl_200it_{tag}')
+    p = read_bal(os.path.join(DATA, str(g['bal'])))
+    e = BAEngine.from_problem(p, fused=fused)
+    e.generate_priors_var(50.0)
+    e.update_all_beliefs()
+    hold_cp, hold_sweep = G15B_HOLD[tag]
+    n_ref = len(g['are'])
+    checkpoints = [int(c) for c in g['checkpoints'] if f'it{int(c)}_cam_eta' in g and int(c) <= 100]      # (beyond: tests/tools/g15b_trace.py)
+    relin, gaps, ages = [], {}, {}
+
+    def grab(i, graph):
+        relin.append(graph.count_relinearising())
+        if i in checkpoints:
+            gaps[i] = belief_gap(graph.beliefs(), g, f'it{i}_')
+            ages[i] = int((graph.iters_since_relin() != g[f'it{i}_iters_since_relin']).sum())
+    ares, _ = oracle_mod.replay_ba(e, min(n_ref, max(checkpoints) + 1), diagnostics=True, on_iter=grab, float_impl=True)
+    print(f"G15b {tag} {'fused' if fused else 'general'}: belief gap per checkpoint", {k: f'{v:.1e}' for k, v in gaps.items()})
+    assert np.array_equal(np.array(relin[:hold_sweep]), g['n_relin'][:hold_sweep])
+    assert np.allclose(ares[:hold_sweep], g['are'][:hold_sweep], rtol=1e-3)
+    held = {k: v for k, v in gaps.items() if k <= hold_cp}
+    assert max(held.values()) < 1e-4 and all(ages[k] == 0 for k in held), (gaps, ages)
+    if tag in G15B_NEAR:
+        k, bound = G15B_NEAR[tag]
+        assert gaps[k] < bound, gaps
     e.close()

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA, belief_gap, golden, rel_err_rows
+from conftest import DATA, G15B_HOLD, G15B_NEAR, belief_gap, golden, rel_err_rows
 from gbp_amd.balio import read_bal
 from gbp_amd.synthetic import BAProblem, make_synthetic
 
@@ -408,3 +408,34 @@ def test_g15_float_implementation_through_relinearisation(oracle_mod, tag):
     assert sorted(gaps) == list(checkpoints) and gaps[12] < 1e-6 and max(gaps.values()) < G15_BELIEF_TOL, gaps
     pl = o.priors()[3][:, 0, 0]
     assert np.allclose(pl, g['lmk_prior_lambda'], rtol=1e-10)
+
+
+@pytest.mark.parametrize('tag', ['vsmall', 'small'])
+def test_g15b_float_implementation_at_ba_default_length(oracle_mod, tag):
+    """the C oracle against the reference's own `ba.py --float_implementation` run at the default 200 sweeps -- as far as the reference
+    gets (see G15B_HOLD in conftest.py).  The GPU twin is in tests/test_long_run_gpu.py."""
+    g = golden(f'G15b_floatimpl_200it_{tag}')
+    assert int(g['reference_failed_in_sweep']) == (143 if tag == 'small' else -1)
+    if tag == 'small':
+        assert 'Singular matrix' in str(g['reference_error']) and g['are'][140] > 1e4      # the reference itself has blown up by then
+    p = read_bal(os.path.join(DATA, str(g['bal'])))
+    o = oracle_mod.OracleBA.from_problem(p)
+    o.generate_priors_var(50.0)
+    o.update_all_beliefs()
+    hold_cp, hold_sweep = G15B_HOLD[tag]
+    checkpoints = [int(c) for c in g['checkpoints'] if f'it{int(c)}_cam_eta' in g and int(c) <= max(hold_cp, G15B_NEAR.get(tag, (0, 0))[0])]
+    relin, gaps, ages = [], {}, {}
+
+    def grab(i, graph):
+        relin.append(int((graph.relin_state()['iters_since_relin'] == 0).sum()))
+        if i in checkpoints:
+            gaps[i] = belief_gap(graph.beliefs(), g, f'it{i}_')
+            ages[i] = int((graph.relin_state()['iters_since_relin'] != g[f'it{i}_iters_since_relin']).sum())
+    ares, _ = oracle_mod.replay_ba(o, max(hold_sweep, max(checkpoints)) + 1, diagnostics=True, on_iter=grab, float_impl=True)
+    assert np.array_equal(np.array(relin[:hold_sweep]), g['n_relin'][:hold_sweep])
+    assert np.allclose(ares[:hold_sweep], g['are'][:hold_sweep], rtol=1e-3)
+    held = {k: v for k, v in gaps.items() if k <= hold_cp}
+    assert max(held.values()) < 1e-4 and all(ages[k] == 0 for k in held), (gaps, ages)
+    if tag in G15B_NEAR:
+        k, bound = G15B_NEAR[tag]
+        assert gaps[k] < bound, gaps

@@ -122,7 +122,7 @@ def test_bench_n_ranks_on_one_gpu(tmp_path, world):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(GBP_BENCH_SHARE_GPU='1', GBP_XCHG_BLOCKS='16', HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_PEER_TIMEOUT_MS='20000')
     cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(world), '--steps', '20', '--warmup', '5',
-           '--backend', 'gloo', '--exchange', 'peer', '--single-batch']          # the headline graph: parity_check has its fixture
+           '--backend', 'gloo', '--exchange', 'peer', '--single-batch', '--secondary-lmks', str(8000 * world)]      # the headline graph: parity_check has its fixture
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -146,6 +146,36 @@ def test_bench_n_ranks_on_one_gpu(tmp_path, world):
     assert pc['ok'] is True and pc['camera_beliefs_bitwise_equal_across_ranks'] is True and pc['ranks_reported_by_exchange'] == world
     assert pc['camera_belief_gap_vs_reference'] < 1e-6 and pc['are_trace_max_rel_err'] < 1e-6 and len(pc['are_trace']) == 11
     assert pc['distinct_devices'] == 1 and pc['one_rank_per_device'] is False      # (the ranks share this box's one GPU, and the line says so)
+    # the node's topology, the stated model of the step, and the bandwidth-bound companion travel in the line
+    topo = cfg['topology']
+    assert topo['shared_gpu'] is True and topo['ranks'] == world and topo['devices'] == 1
+    pred = out['prediction']
+    assert out['predicted_step_ms'] == pred['predicted_step_ms'] and 0.005 < pred['predicted_step_ms'] < 1.0
+    assert len(pred['solo_step_ms_per_rank']) == world and max(pred['solo_step_ms_per_rank']) == pred['predicted_step_ms']
+    assert pred['measured_step_ms'] == pytest.approx(out['ms_per_step'], rel=1e-9)
+    sec = out['secondary']
+    assert sec['label'].startswith('SECONDARY') and sec['n_factors'] == 80_000 * world and sec['value'] > 0 and sec['exchange'] == 'peer'
+    assert len(sec['per_rank']) == world and all(pr['n_factors'] == 80_000 and pr['ranks_reported_by_exchange'] == world for pr in sec['per_rank'])
+
+
+def test_bench_line_survives_an_rccl_that_does_not_come_up(tmp_path):
+    """`--exchange rccl` on a node whose RCCL fails at init (GBP_RCCL_FAIL: gbp_ba_comm_unique_id refuses on rank 0, the
+    refusal travels to every rank as data).  The job must not die: ShardedBA falls back -- here, with a gloo side channel, to the
+    Python-driven loop -- and the ONE line says which exchange ran and why the requested one did not."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(GBP_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GBP_RCCL_FAIL='1')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '2', '--backend', 'gloo', '--exchange', 'rccl',
+           '--single-batch', '--secondary-lmks', '0']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    cfg = out['config']
+    assert cfg['exchange_requested'] == 'rccl' and cfg['exchange'] == 'python' and cfg['loop'] == 'python'
+    assert 'GBP_RCCL_FAIL' in cfg['exchange_fallback'], cfg
+    assert out['value'] > 0 and out['parity_check']['ok'] is True and out['parity_check']['camera_beliefs_bitwise_equal_across_ranks'] is True
 
 
 def test_peer_selftest_names_the_pair_that_failed(tmp_path):

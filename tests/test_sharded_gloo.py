@@ -50,6 +50,31 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_local(rank, world, port, out_dir):
+    """the same job, every rank handing over ITS shard only (ShardedBA(local_shard=True))"""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gbp_amd.balio import read_bal
+    from gbp_amd.sharded import ShardedBA, local_problem, partition_landmarks
+    from oracle import oracle
+    p = read_bal(os.path.join(DATA, 'fr1desk_small.txt'))
+    b = partition_landmarks(p.lmk_idx, p.n_lmks, world)
+    mine = local_problem(p, int(b[rank]), int(b[rank + 1]))
+    del p
+    g = ShardedBA(mine, engine_factory=_OracleAdapter, local_shard=True)
+    g.generate_priors_var(50.0)
+    g.update_all_beliefs()
+    ares, _ = oracle.replay_ba(g, 12, diagnostics=True)
+    ce, cl = g.camera_beliefs()
+    (lo, hi), le, ll = g.local_landmark_beliefs()
+    np.savez(os.path.join(out_dir, f'local{rank}.npz'), ce=ce, cl=cl, le=le, ll=ll, lo=lo, hi=hi, ares=ares, F=g.F, F_total=g.F_total, L_total=g.L_total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_partition_is_balanced_and_complete():
     from gbp_amd.balio import read_bal
     from gbp_amd.sharded import partition_landmarks, local_problem
@@ -88,3 +113,19 @@ def test_two_rank_sweep_matches_single_process(tmp_path, oracle_mod):
     assert rel_err_rows(le2, le) < 1e-7 and rel_err_rows(ll2, ll) < 1e-7
     assert np.allclose(r0['ares'], ares, rtol=1e-8)
     assert float(r0['energy']) == pytest.approx(o.energy(), rel=1e-7)
+
+
+@pytest.mark.timeout(300)
+def test_ranks_that_bring_their_own_shard(tmp_path, oracle_mod):
+    """ShardedBA(local_shard=True): every rank hands over its own landmarks + the shared cameras (bench.py's secondary workload makes
+    them on the rank).  Cut from the same file by the same partition, the job must be the one the whole-problem constructor runs: bitwise."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_local, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        a, b = np.load(os.path.join(tmp_path, f'rank{r}.npz')), np.load(os.path.join(tmp_path, f'local{r}.npz'))
+        for k in ('ce', 'cl', 'le', 'll', 'ares'):
+            assert np.array_equal(a[k], b[k]), (r, k)
+        assert (int(a['lo']), int(a['hi']), int(a['F'])) == (int(b['lo']), int(b['hi']), int(b['F']))
+        assert int(b['F_total']) == 3917 and int(b['L_total']) > 0
