@@ -265,7 +265,8 @@ def parity_check(graph, problem, dist, torch, side_dev, world, local_rank, n_swe
         dist.all_gather_object(ids, me)
         out["distinct_devices"] = len(set(ids))
         out["one_rank_per_device"] = len(set(ids)) == world
-    if hasattr(graph, 'comm_info'):
+    in_library = getattr(graph, 'library_loop', True)            # (the Python-driven loop exchanges through torch.distributed: the library has no rank count to report)
+    if hasattr(graph, 'comm_info') and in_library:
         try:
             out["ranks_reported_by_exchange"] = int(graph.comm_info()['n_ranks'])
         except Exception:                                        # noqa: BLE001
@@ -282,7 +283,7 @@ def parity_check(graph, problem, dist, torch, side_dev, world, local_rank, n_swe
         out["are_trace_max_rel_err"] = float(np.max(np.abs(np.asarray(ares) - ref) / np.abs(ref)))
         ok = out["camera_belief_gap_vs_reference"] < 1e-6 and out["are_trace_max_rel_err"] < 1e-6
         if world > 1:
-            ok = ok and out.get("camera_beliefs_bitwise_equal_across_ranks", False) and out.get("ranks_reported_by_exchange") == world
+            ok = ok and out.get("camera_beliefs_bitwise_equal_across_ranks", False) and (not in_library or out.get("ranks_reported_by_exchange") == world)
         out["ok"] = bool(ok)
         out["tolerance"] = "camera beliefs (eta, Lambda) 1e-6 relative per camera, ARE 1e-6 relative per sweep (BASELINE north_star: 1e-4)"
     return out
@@ -752,7 +753,7 @@ def main(shard_factory=None, script=None):
                        "sweep": "fused" if fused else "general",
                        "topology": topology,
                        "camera_windows": {"widest": plan['max_window'], "table_rows": plan['table_rows']} if plan.get('max_window') else None,
-                       "loop": ("python" if (args.python_loop or dry) else "in-library") if (world > 1 or args.sharded) else "gbp_ba_iterate"},
+                       "loop": ("python" if (args.python_loop or dry or not getattr(graph, 'library_loop', True)) else "in-library") if (world > 1 or args.sharded) else "gbp_ba_iterate"},
             "timing": {"protocol": "state restored before every batch; W warm-up + K timed sweeps between barrier+synchronize; median over batches",
                        "batches": int(times.size), "timed_seconds": float(times.sum()),
                        "ms_per_step_median": ms_step, "ms_per_step_min": dt_min / args.steps * 1e3,

@@ -169,7 +169,7 @@ int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t fla
         }
         pe.finegrained = true;
     }
-    HIPCHK(hipMemsetAsync(pe.mailbox, 0, bytes, h->stream));
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pe.mailbox), (int)PEER_EMPTY32, bytes / 4, h->stream));      // every slot empty (gbp_kernels.hpp: the data is its own arrival flag)
     if (!pe.d_ctl) HIPCHK(hipMalloc(reinterpret_cast<void **>(&pe.d_ctl), 4 * sizeof(int)));
     HIPCHK(hipMemsetAsync(pe.d_ctl, 0, 4 * sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -228,7 +228,7 @@ int gbp::sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_reli
 }
 
 
-int gbp::launch_peer_selftest(gbp_ba *h, const PeerOut &po, const double *mine, int rank, long long ticks, int *d_out)
+int gbp::launch_peer_selftest(gbp_ba *h, const PeerOut &po, double *mine, int rank, long long ticks, int *d_out)
 {
     hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(64), 0, h->stream, po, mine, rank, ticks, d_out);
     HIPCHK(hipGetLastError());

@@ -108,6 +108,40 @@ GBP_DEV double2 ld2_nt(const double *__restrict__ base, unsigned byte_off)
     return make_double2(v.x, v.y);
 }
 
+// L2 TOUCH-PREFETCH (round 6).  The sweep takes 65 us where its memory traffic alone takes 44 and its arithmetic 27: a wave has loads
+// in flight only between the top of an iteration and the arrival of its streams, and none while it does its maths -- eight waves per
+// CU are then too few requests in flight to keep the memory system busy.  Loading the NEXT tile's streams into registers during the
+// maths was built three times (rounds 2, 3, 4: 84-108 us: 44 more live registers, the stores queue behind eleven more 1 KB loads).
+// This needs neither: after its own stream loads a wave touches one byte of every 64 bytes of the tile that will be taken
+// GBP_PF_DIST tickets later (three instructions, the loaded bytes are thrown away), so that the 11 KB block is on its way into the
+// XCD's L2 -- 4 MB, 128 KB per CU: eight tiles ahead is 88 KB -- while this wave and its neighbours compute; whichever wave draws
+// that ticket finds its streams one L2 hit away instead of one trip to the memory side.
+#ifndef GBP_PF_DIST
+#define GBP_PF_DIST 0
+#endif
+#ifndef GBP_PF_STRIDE
+#define GBP_PF_STRIDE 64
+#endif
+struct Touch { unsigned v[3]; };
+template <bool NT>
+GBP_DEV void touch_tile(const Params &p, int t, int lane, Touch &o)
+{
+    constexpr int LIN_B = LIN_ROWS * WTILE * 8, MSG_B = MSG_ROWS * WTILE * 8, N_LIN = LIN_B / GBP_PF_STRIDE, N = (LIN_B + MSG_B) / GBP_PF_STRIDE;
+    const char *lin_t = reinterpret_cast<const char *>(p.lin + (size_t)t * (LIN_ROWS * WTILE));
+    const char *msg_t = reinterpret_cast<const char *>(p.msg + (size_t)t * (MSG_ROWS * WTILE));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = j * 64 + lane;
+        o.v[j] = 0;
+        if (j * 64 < N && i < N) {
+            const unsigned char *q = reinterpret_cast<const unsigned char *>(i < N_LIN ? lin_t + i * GBP_PF_STRIDE : msg_t + (i - N_LIN) * GBP_PF_STRIDE);
+            o.v[j] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+    }
+}
+// the loaded bytes must be waited for somewhere (their registers are dead otherwise and would be handed out while the loads are in flight)
+GBP_DEV void touch_retire(const Touch &o) { asm volatile("" ::"v"(o.v[0]), "v"(o.v[1]), "v"(o.v[2])); }
+
 // nt: bit 0 = the lin rows (x0 | z | variance) stream PAST the memory-side cache, bit 1 = the message rows too (nontemporal loads:
 // no allocation in the 256 MiB Infinity Cache).  The fused sweep of a graph whose whole working set fits that cache uses neither (at the
 // headline size bypassing it costs +12...18 us); a larger graph sends the tiles that do not fit past it, loads and stores, so that the
@@ -163,8 +197,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     if (WINDOWED) {
         const int4 w = a.win[blockIdx.x];
         cam_base = __builtin_amdgcn_readfirstlane(w.x); cam_count = __builtin_amdgcn_readfirstlane(w.y); row_off = __builtin_amdgcn_readfirstlane(w.z);
-        unsigned short *map = reinterpret_cast<unsigned short *>(ctl + 2);
-        for (int i = tid; i < cam_count; i += NWAVES * 64) map[a.wgcams[row_off + i] - cam_base] = (unsigned short)i;
+        // behind the control words: where table row k goes (rowidx, fetched NOW: read at the write-out it was a dependent global load in
+        // front of every 16-byte store, after everything else had finished), then the 16-bit map camera -> table row
+        int *rowl = ctl + 2;
+        unsigned short *map = reinterpret_cast<unsigned short *>(rowl + win_rows_ints(a.acc_doubles / 27));
+        for (int i = tid; i < cam_count; i += NWAVES * 64) {
+            map[a.wgcams[row_off + i] - cam_base] = (unsigned short)i;
+            rowl[i] = a.rowidx[row_off + i];
+        }
     }
     for (int i = tid; i < a.acc_doubles; i += NWAVES * 64) acc[i] = 0.0;
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
@@ -214,6 +254,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         // camera rows: nontemporal message stores as well as loads, 116.6-117.3 against 119.4-119.7 us per sweep with plain stores)
         const bool past = STAGED || (PINNED && (t - tb) >= a.pin);
         issue_streams<LOSS, STAGED>(p, t, lane, S, past ? 3 : (PINNED ? a.nt : 0));      // (FusedArgs::nt: experiments with the pinned variant only)
+#if GBP_PF_DIST > 0
+        Touch pf;
+        bool pf_on = false;
+        if (!STAGED) {
+            const int tip = ti + GBP_PF_DIST;                  // (wave-uniform)
+            if (tip < ntl) {
+                const int tp = tb + (a.reverse ? ntl - 1 - tip : tip);
+                if (PINNED && (tp - tb) >= a.pin) touch_tile<true>(p, tp, lane, pf); else touch_tile<false>(p, tp, lane, pf);
+                pf_on = true;
+            }
+        }
+#endif
         const unsigned lo = (unsigned)lane * 16u;
         double x0[9], z[2], avar = p.sigma2, qC[2], qL[2], WC[3], VL[3], muC[6], PC[21];
         const unsigned long long words = (unsigned long long)__double_as_longlong(S.a[5].y);      // meta (low) | state (high): gbp_kernels.hpp ROW_SM
@@ -268,6 +320,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         }
         asm volatile("" ::: "memory");
         GBP_PH(4);                                         // camera gather
+#if GBP_PF_DIST > 0
+        if (pf_on) touch_retire(pf);                       // (issued right behind the streams: long since back when the gather has arrived)
+#endif
 
         // landmark heads -> wave scratch -> the lanes of their factors
 #pragma unroll
@@ -347,7 +402,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         asm volatile("" ::: "memory");
         GBP_PH_NOWAIT(8);                                  // waiting for the accumulation turn
         const int rank = state_rank(st);
-        const int cloc = WINDOWED ? (active ? (int)reinterpret_cast<const unsigned short *>(ctl + 2)[cam - cam_base] : 0) : cam - cam_base;
+        const int cloc = WINDOWED ? (active ? (int)reinterpret_cast<const unsigned short *>(ctl + 2 + win_rows_ints(a.acc_doubles / 27))[cam - cam_base] : 0) : cam - cam_base;
         const bool mine = active && (WINDOWED || (unsigned)cloc < (unsigned)cam_count);
         // Lanes of a tile that hit the same camera add in rank (= lane) order.  Few of them: one round per rank, one lane per camera in
         // every ds_add_f64.  Many (graphs with a few dozen cameras: fr1desk has 63, and up to eight factors of a tile on one of them):
@@ -378,7 +433,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     for (int i = tid; i < (WINDOWED ? cam_count : a.acc_doubles / 27) * (TROW / 2); i += NWAVES * 64) {
         const int c = i / (TROW / 2), k = 2 * (i - c * (TROW / 2));
         const double2 v = make_double2(acc[c * 27 + k], k + 1 < 27 ? acc[c * 27 + k + 1] : 0.0);
-        const size_t row = WINDOWED ? (size_t)a.rowidx[row_off + c] : (size_t)(cam_base + c) * gridDim.x + blockIdx.x;
+        const size_t row = WINDOWED ? (size_t)(ctl + 2)[c] : (size_t)(cam_base + c) * gridDim.x + blockIdx.x;
         *reinterpret_cast<double2 *>(a.block_partials + row * TROW + k) = v;
     }
     GBP_PH(11);                                            // table write-out

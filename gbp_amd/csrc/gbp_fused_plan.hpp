@@ -114,8 +114,13 @@ inline size_t fused_shmem(int C)
     return sizeof(double) * ((size_t)((acc_doubles + 1) & ~1) + WAT_WAVES * WAVE_LDS_DOUBLES + 1);
 }
 
-// camera windows: a table of `set` cameras, the per-wave scratch and the 16-bit map over an interval of `width` cameras
-inline size_t fused_shmem_windows(int set, int width) { return fused_shmem(std::max(set, 1)) + (((size_t)width * 2 + 7) & ~(size_t)7); }
+// camera windows: a table of `set` cameras, the per-wave scratch, the rows' destinations (one int per table row) and the 16-bit map
+// over an interval of `width` cameras
+__host__ __device__ constexpr int win_rows_ints(int set) { return (set + 1) & ~1; }
+inline size_t fused_shmem_windows(int set, int width)
+{
+    return fused_shmem(std::max(set, 1)) + (size_t)win_rows_ints(std::max(set, 1)) * sizeof(int) + (((size_t)width * 2 + 7) & ~(size_t)7);
+}
 
 // most cameras whose table + the per-wave scratch fit the LDS (the plan falls back to the general sweep above it)
 inline int fused_max_cams()

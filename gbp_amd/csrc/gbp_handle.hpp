@@ -235,7 +235,7 @@ int sweep_begin(gbp_ba *h, int with_messages, int robustify, int local_relin, do
                 bool defer_big = false, const PeerOut *peer = nullptr, const PeerWait *merged = nullptr);
 int launch_cam_finish(gbp_ba *h, const double *gathered, int n_parts, size_t stride, const PeerWait *wait = nullptr);
 int launch_finish_parts(gbp_ba *h, hipStream_t stream);      // beliefs of the landmarks that span tiles (after a sweep's factor kernel)
-int launch_peer_selftest(gbp_ba *h, const PeerOut &po, const double *mine, int rank, long long ticks, int *d_out);
+int launch_peer_selftest(gbp_ba *h, const PeerOut &po, double *mine, int rank, long long ticks, int *d_out);
 int enable_remainder(gbp_ba *h);
 int remainder_drop(gbp_ba *h);
 int remainder_guard(gbp_ba *h, int local_relin, int no_test);

@@ -527,25 +527,36 @@ GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
 
 // ------------------------------------------------------------------ peer-store camera exchange --
 // Landmark-sharded sweep without a collective call: every rank owns a MAILBOX in its own
-// device memory -- two sweep-parity halves of [n_ranks][C] rows of 28 doubles: a camera's 27 partial sums and a tag -- and the
+// device memory -- two sweep-parity halves of [n_ranks][C] rows of 28 doubles: a camera's 27 partial sums + pad -- and the
 // kernel that produces a rank's camera partial sums stores each row straight into the mailbox of EVERY rank (xGMI peer stores
-// on a multi-GPU node) and then raises the row's tag to the exchange number; whoever finishes camera c waits for the n_ranks tags
-// of row c in its own mailbox half and adds the parts in rank order.  Two halves are enough: a rank can write sweep k+2's sums only
-// after its own finish of sweep k+1, which needs every peer's sums of sweep k+1, which a peer produces after ITS finish of sweep k.
+// on a multi-GPU node); whoever finishes camera c polls the n_ranks rows c in its own mailbox half and adds the parts in rank order.
+// Two halves are enough: a rank can write sweep k+2's sums only after its own finish of sweep k+1, which needs every peer's sums of
+// sweep k+1, which a peer produces after ITS finish of sweep k.
+//
+// ONE trip per exchange (round 6).  THE DATA IS ITS OWN ARRIVAL FLAG: an empty mailbox slot holds PEER_EMPTY -- a quiet NaN with a
+// payload no arithmetic produces -- the sender just stores its 27 doubles (each an 8-byte single-copy-atomic store, fire and forget),
+// the finisher's poll IS its data load (repeat until no slot of the row is empty), and it puts PEER_EMPTY back into the slots it has
+// read -- by the two-halves argument above that reset is long complete (a kernel boundary and a whole exchange lie in between) before
+// any peer stores into the slot again.  Rounds 3-5 stored the row, waited for the stores' acknowledgements (s_waitcnt vmcnt(0): data
+// before tag), raised a tag, and the finisher polled the tag and THEN loaded the row: four dependent memory round trips per exchange --
+// across xGMI each is microseconds -- where this has two (the stores' flight, the poll that finds them), and no ordering between
+// different addresses is asked of the link at all.
 //
 // No fences: a system-scope release / acquire fence on gfx950 writes back / invalidates a whole L2 (8000 waves doing that after the
 // sweep cost 120 us per reduce launch).  Every mailbox access is itself a system-scope relaxed atomic -- write-through stores, loads
-// that bypass the caches -- and "data before tag" is the s_waitcnt vmcnt(0) of the ONE wave that stores both: its data stores have
-// been acknowledged before it issues the tag store (/opt/skills/guides/MI355X_MICROARCH.md, hand-off with a separate flag).
+// that bypass the caches (/opt/skills/guides/MI355X_MICROARCH.md).
 constexpr int MAX_PEERS = 16;
-constexpr int PEER_ROW = 28;                          // doubles per mailbox row: 27 sums | tag (the exchange number, as 64 bits)
+constexpr int PEER_ROW = 28;                          // doubles per mailbox row: 27 sums | pad (rows start on 16 bytes)
+constexpr unsigned PEER_EMPTY32 = 0x7ff87ff8u;        // both halves of PEER_EMPTY (the mailbox is filled with hipMemsetD32Async)
+constexpr unsigned long long PEER_EMPTY = ((unsigned long long)PEER_EMPTY32 << 32) | PEER_EMPTY32;      // a quiet NaN with a payload: arithmetic makes 0x7ff8000000000000 (or its negative), and it propagates payloads only from operands that carry one
+constexpr int PEER_CHUNK = 8;                         // rows of a camera polled together (one trip for up to eight ranks)
 struct PeerOut {
     int n;                                            // ranks (0: no peer stores)
     double *dst[MAX_PEERS];                           // rank r's mailbox half of this sweep, the block of THIS rank: [C][PEER_ROW]
-    unsigned long long seq;                           // exchange number (1, 2, ...): the value the tags are raised to
+    unsigned long long seq;                           // exchange number (1, 2, ...): the self-test's probe values depend on it
 };
 struct PeerWait {
-    const double *src;                                // this rank's mailbox half: [n_parts][C][PEER_ROW], or NULL (parts are plain arrays)
+    double *src;                                      // this rank's mailbox half: [n_parts][C][PEER_ROW], or NULL (parts are plain arrays)
     unsigned long long seq;
     long long timeout_ticks;                          // wall_clock64 ticks (100 MHz): a peer that never arrives must not hang the GPU
     int *err;                                         // set to 1 on time-out (reported by gbp_ba_sync)
@@ -554,48 +565,62 @@ struct PeerWait {
 
 GBP_DEV void peer_store(double *dst, double v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 GBP_DEV double peer_load(const double *src) { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+GBP_DEV bool peer_is_empty(double v) { return (unsigned long long)__double_as_longlong(v) == PEER_EMPTY; }
+GBP_DEV double peer_empty_value() { return __longlong_as_double((long long)PEER_EMPTY); }
 
-// ONE wave: lanes 0..26 hold camera c's partial sums; row c of this rank's block in every mailbox gets them, then the tag
+// ONE wave: lanes 0..26 hold camera c's partial sums; row c of this rank's block in every mailbox gets them.  Nothing to wait for.
 GBP_DEV void peer_push_row(const PeerOut &peer, int c, double v, int lane)
 {
     for (int r = 0; r < peer.n; ++r)
         if (lane < 27) peer_store(peer.dst[r] + (size_t)c * PEER_ROW + lane, v);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through data stores have been acknowledged
-    if (lane == 0)
-        for (int r = 0; r < peer.n; ++r)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer.dst[r] + (size_t)c * PEER_ROW + 27), peer.seq, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ONE wave: wait until all n_parts ranks have delivered row c of this exchange (one lane per rank polls); false on time-out
-GBP_DEV bool peer_wait_row(const PeerWait &wait, int n_parts, int C, int c, int lane)
+// ONE wave: entry `lane` (< 27) of rows c of parts r0 .. r0 + PEER_CHUNK - 1 (those below n_parts) of the mailbox half `src`
+// ([n_parts][C][PEER_ROW]), polled until none of them is empty, then emptied again for the exchange after next.  false on time-out.
+GBP_DEV bool peer_take_rows(const PeerWait &wait, int n_parts, int C, int c, int r0, int lane, double (&v)[PEER_CHUNK], long long t0)
 {
     bool ok = true;
-    if (lane < n_parts) {
-        const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(wait.src + ((size_t)lane * C + c) * PEER_ROW + 27);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != wait.seq) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > wait.timeout_ticks) { ok = false; break; }
+    for (;;) {
+        bool missing = false;
+#pragma unroll
+        for (int j = 0; j < PEER_CHUNK; ++j) {
+            v[j] = 0.0;
+            if (lane < 27 && r0 + j < n_parts) {
+                v[j] = peer_load(wait.src + ((size_t)(r0 + j) * C + c) * PEER_ROW + lane);
+                missing = missing || peer_is_empty(v[j]);
+            }
         }
+        if (!__any(missing)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > wait.timeout_ticks) { ok = false; break; }
     }
     ok = __all(ok);
-    if (!ok && lane == 0) atomicExch(wait.err, 1);
-    return ok;
+    if (!ok) {
+        if (lane == 0) atomicExch(wait.err, 1);
+        return false;
+    }
+#pragma unroll
+    for (int j = 0; j < PEER_CHUNK; ++j)
+        if (lane < 27 && r0 + j < n_parts) peer_store(wait.src + ((size_t)(r0 + j) * C + c) * PEER_ROW + lane, peer_empty_value());
+    return true;
 }
 
 // belief_c = prior_c + sum over parts (fixed order) of part_r[c]; mu_c = Lambda^-1 eta.  One wavefront per camera: lane k < 27
-// adds entry k of the parts (coalesced 216-byte rows) in rank order, lane 0 collects the 27 sums and solves the 6x6.
-// With wait.src the parts are rows of a mailbox half: the camera's wave polls the n_parts tags of its row first (one lane per rank).
+// adds entry k of the parts (coalesced 216-byte rows) in rank order, seven lanes solve the 6x6.
+// With wait.src the parts are rows of a mailbox half: the camera's wave takes them as they arrive (peer_take_rows).
 // one WAVE finishes camera c (shared by k_cam_finish and the merged reduce-exchange-finish kernel of gbp_fused.hpp)
 GBP_DEV void cam_finish_wave(const Params &p, const double *gathered, int n_parts, size_t part_stride, const PeerWait &wait, int c, int lane)
 {
     double acc = 0.0;
     if (wait.src) {                                         // the parts are rows of this rank's mailbox half
-        peer_wait_row(wait, n_parts, p.C, c, lane);
-        if (lane < 27) {
-            acc = p.cprior[(size_t)c * 27 + lane];
-            for (int r = 0; r < n_parts; ++r) acc += peer_load(wait.src + ((size_t)r * p.C + c) * PEER_ROW + lane);
+        if (lane < 27) acc = p.cprior[(size_t)c * 27 + lane];
+        const long long t0 = wall_clock64();
+        for (int r0 = 0; r0 < n_parts; r0 += PEER_CHUNK) {
+            double v[PEER_CHUNK];
+            if (!peer_take_rows(wait, n_parts, p.C, c, r0, lane, v, t0)) break;      // (time-out: reported by gbp_ba_sync, the belief is garbage)
+#pragma unroll
+            for (int j = 0; j < PEER_CHUNK; ++j)
+                if (r0 + j < n_parts) acc += v[j];         // rank order
         }
     } else if (lane < 27) {
         acc = p.cprior[(size_t)c * 27 + lane];

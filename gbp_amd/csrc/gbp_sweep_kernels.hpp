@@ -203,8 +203,8 @@ __global__ __launch_bounds__(NT) void k_cam_partial_staged(Params p, double *__r
 
 // The general sweep under the peer-store exchange, everything after the factor kernel in ONE launch (the staged counterpart of
 // k_cam_reduce_xchg, gbp_fused.hpp): a grid of persistent workgroups, never larger than what is resident at once, first sums and
-// PUSHES all of its cameras (staged rows -> 27 sums -> row c of every rank's mailbox + tag), then finishes them, one wave per camera
-// (wait for the n_ranks tags of row c, add the parts in rank order, prior, mean | covariance).  Same sums, bitwise, as
+// PUSHES all of its cameras (staged rows -> 27 sums -> row c of every rank's mailbox), then finishes them, one wave per camera
+// (take the n_ranks rows c as they arrive, add the parts in rank order, prior, mean | covariance).  Same sums, bitwise, as
 // k_cam_partial_staged + k_peer_push + k_cam_finish, which remain the path of logical ranks that share one device (rendezvous hook).
 template <int NT>
 __global__ __launch_bounds__(NT) void k_cam_staged_xchg(Params p, double *__restrict__ partial, PeerOut peer, PeerWait wait)
@@ -281,36 +281,32 @@ __global__ __launch_bounds__(BLOCK) void k_cam_partial(Params p, double *__restr
 
 
 // Self-test of the peer-store exchange, run by every rank after gbp_ba_peer_connect and before the first sweep (gbp_ba_peer_selftest): ONE
-// wave stores a tagged probe row -- 27 values that depend on (sender, entry, test number) -- into the probe area of EVERY rank's mailbox
-// exactly the way the sweep's rows travel (write-through data stores, s_waitcnt, tag store), then waits for the probe rows of all
-// ranks in its own mailbox and compares every entry.  out[0] |= 1: a rank's row did not arrive in time, |= 2: it arrived with wrong
-// contents; out[1] = the (lowest) rank concerned.  A pair of devices whose mapping, atomics or ordering do not work shows up here, with a
-// name, instead of as a time-out or a wrong belief in the middle of a run.
+// wave stores a probe row -- 27 values that depend on (sender, entry, test number) -- into the probe area of EVERY rank's mailbox
+// exactly the way the sweep's rows travel (write-through stores into slots that hold PEER_EMPTY), then polls the probe rows of all
+// ranks in its own mailbox until none of their slots is empty, compares every entry and empties them again.  out[0] |= 1: a rank's row
+// did not arrive in time, |= 2: it arrived with wrong contents; out[1] = the (lowest) rank concerned.  A pair of devices whose mapping or
+// atomics do not work shows up here, with a name, instead of as a time-out or a wrong belief in the middle of a run.
 GBP_HD double peer_probe_value(int src, int k, unsigned long long seq) { return (double)(((long long)(src + 1) << 20) + ((long long)k << 12) + (long long)(seq & 0xfffu)); }     // (an integer: exact however it is evaluated)
-__global__ __launch_bounds__(64) void k_peer_selftest(PeerOut peer, const double *mine, int rank, long long timeout_ticks, int *out)
+__global__ __launch_bounds__(64) void k_peer_selftest(PeerOut peer, double *mine, int rank, long long timeout_ticks, int *out)
 {
     const int lane = threadIdx.x;
     for (int r = 0; r < peer.n; ++r)
         if (lane < 27) peer_store(peer.dst[r] + lane, peer_probe_value(rank, lane, peer.seq));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-        for (int r = 0; r < peer.n; ++r)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer.dst[r] + 27), peer.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    bool arrived = true;
-    if (lane < peer.n) {
-        const unsigned long long *tag = reinterpret_cast<const unsigned long long *>(mine + (size_t)lane * PEER_ROW + 27);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer.seq) {
+    unsigned long long late = 0ull, wrong = 0ull;
+    const long long t0 = wall_clock64();
+    for (int r = 0; r < peer.n; ++r) {
+        double v = 0.0;
+        bool arrived = true;
+        for (;;) {
+            bool missing = false;
+            if (lane < 27) { v = peer_load(mine + (size_t)r * PEER_ROW + lane); missing = peer_is_empty(v); }
+            if (!__any(missing)) break;
             __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > timeout_ticks) { arrived = false; break; }
         }
-    }
-    const unsigned long long late = __ballot(!arrived);
-    unsigned long long wrong = 0ull;
-    for (int r = 0; r < peer.n; ++r) {
-        if ((late >> r) & 1ull) continue;
-        const bool bad = lane < 27 && peer_load(mine + (size_t)r * PEER_ROW + lane) != peer_probe_value(r, lane, peer.seq);
-        if (__ballot(bad)) wrong |= 1ull << r;
+        if (!__all(arrived)) { late |= 1ull << r; continue; }
+        if (__ballot(lane < 27 && v != peer_probe_value(r, lane, peer.seq))) wrong |= 1ull << r;
+        if (lane < 27) peer_store(mine + (size_t)r * PEER_ROW + lane, peer_empty_value());
     }
     if (lane == 0 && (late | wrong)) {
         out[0] = (late ? 1 : 0) | (wrong ? 2 : 0);
