@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     LmkPre pre;
 #pragma unroll
     for (int b = 0; b < LMK_PASSES; ++b) pre.pri[b] = 0.0;
-    pre.rows = 0;
+    pre.rx = 0; pre.ry = 0;
     int n_relin = 0;                                      // factors of this wave's tiles that relinearised (wave-uniform)
     GBP_PH_DECL;
 

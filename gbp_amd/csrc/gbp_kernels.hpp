@@ -197,10 +197,9 @@ GBP_HD bool factor_decide(const Params &p, const double (&x0)[9], const double (
 }
 
 // Factor.compute_factor in compact form (gbp.py:267-294): J = [Jc | Jl], rho = J x0 + z - h(x0), s = 1 / adaptive var
-GBP_HD void factor_linearise(const Params &p, const double (&x0)[9], const double (&z)[2], double avar, double d, Lin &L)
+// (factor_geometry: the part that needs nothing but the linearisation point and the measurement)
+GBP_HD void factor_geometry(const Params &p, const double (&x0)[9], const double (&z)[2], Lin &L)
 {
-    L.d = d;
-    L.s = rcp(avar);
     double h[2];
     linearise(x0, p.K, L.Jc, L.Jl, h);
 #pragma unroll
@@ -212,6 +211,12 @@ GBP_HD void factor_linearise(const Params &p, const double (&x0)[9], const doubl
         for (int i = 0; i < 3; ++i) acc += L.Jl[r][i] * x0[6 + i];
         L.rho[r] = acc + z[r] - h[r];
     }
+}
+GBP_HD void factor_linearise(const Params &p, const double (&x0)[9], const double (&z)[2], double avar, double d, Lin &L)
+{
+    L.d = d;
+    L.s = rcp(avar);
+    factor_geometry(p, x0, z, L);
 }
 
 // One factor's sweep in registers (gbp.py:82-84, 64-80, 46-54, 334-373), covariance form (gbp_math.hpp header).
@@ -228,10 +233,24 @@ GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], 
                         double (&qC)[2], double (&qL)[2], double (&WC)[3], double (&VL)[3],
                         double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr)
 {
+    // The factor's geometry at its stored linearisation point -- rotation, projection, the 2x9 Jacobian, rho: a quarter of the
+    // arithmetic -- needs nothing of the beliefs: it comes FIRST, so that it runs while the camera record, the last thing the sweep
+    // gathers, is still on its way (the relinearisation test below is the first instruction to read it; round 5 ran that test first
+    // and every wave sat out the gather's whole round trip).
+    Lin L;
+#ifndef GBP_GEOM_LATE                                        // (-DGBP_GEOM_LATE: round 5's order, for A/B runs)
+    factor_geometry(p, x0, z, L);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(L.rho[0]), "+v"(L.rho[1]));      // (the order is the point: keep the scheduler from sinking it behind the wait)
+#endif
+#endif
     double d;
     const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
-    Lin L;
-    factor_linearise(p, x0, z, avar, d, L);
+#ifdef GBP_GEOM_LATE
+    factor_geometry(p, x0, z, L);
+#endif
+    L.d = d;
+    L.s = rcp(avar);
     double PL[6];
     load_PL(PL);
     double dqC[2] = {d * qC[0], d * qC[1]}, dqL[2] = {d * qL[0], d * qL[1]};      // the old etas' share of the new ones (gbp.py:368)
@@ -414,8 +433,17 @@ constexpr int LMK_PASSES = (TILE_LMKS + 6) / 7;
 constexpr int ROWS_CONT = 1 << 16, ROWS_MORE = 1 << 17;     // flags beside the two 8-bit slot bounds of LmkPre::rows
 struct LmkPre {
     double pri[LMK_PASSES];
-    int rows;
+    int rx, ry;           // lane l < nl: landmark l's slot range as it is stored (absolute slots).  RAW: what the belief phase needs of it
+                          // (lmk_rows) is formed when that phase runs -- formed at the prefetch it made the wave wait for ALL its loads
+                          // (s_waitcnt vmcnt(0)) at the top of every iteration, before the phase that is there to run while they fly
 };
+// the landmark's slots inside tile t, and whether it began before it (ROWS_CONT) / goes on behind it (ROWS_MORE)
+GBP_DEV int lmk_rows(const LmkPre &q, int lane, int t, int nl)
+{
+    if (lane >= nl) return 0;
+    const int a = q.rx - t * WTILE, b = q.ry - t * WTILE;
+    return max(a, 0) | (min(b, WTILE) << 8) | (a < 0 ? ROWS_CONT : 0) | (b > WTILE ? ROWS_MORE : 0);
+}
 GBP_DEV void lmk_prefetch(const Params &p, int lane, int t, int l0, int nl, LmkPre &q)
 {
     const int g = (lane * 57) >> 9, k = lane - g * 9;       // lane / 9 for lane < 64
@@ -425,13 +453,12 @@ GBP_DEV void lmk_prefetch(const Params &p, int lane, int t, int l0, int nl, LmkP
         const int li = b * 7 + g;
         q.pri[b] = (g < 7 && li < nl) ? base[(unsigned)(li * LREC + LR_PRIOR + k)] : 0.0;
     }
-    q.rows = 0;
+    q.rx = 0; q.ry = 0;
     if (lane < nl) {
-        // the landmark's slots inside THIS tile, and whether it began before it (ROWS_CONT) / goes on behind it (ROWS_MORE)
         const int2 r = *reinterpret_cast<const int2 *>(base + (unsigned)(lane * LREC + LR_ROWS));
-        const int a = r.x - t * WTILE, b = r.y - t * WTILE;
-        q.rows = max(a, 0) | (min(b, WTILE) << 8) | (a < 0 ? ROWS_CONT : 0) | (b > WTILE ? ROWS_MORE : 0);
+        q.rx = r.x; q.ry = r.y;
     }
+    (void)t;
 }
 
 // The landmark beliefs of a tile from the wave's LDS scratch wl = [64][9] new messages (eta 3 | Lambda 6 per factor lane): prior +
@@ -443,11 +470,12 @@ GBP_DEV void lmk_prefetch(const Params &p, int lane, int t, int l0, int nl, LmkP
 GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int t, int l0, int nl, const LmkPre &q)
 {
     const int g = (lane * 57) >> 9, k = lane - g * 9;
+    const int my_rows = lmk_rows(q, lane, t, nl);
 #pragma unroll
     for (int b = 0; b < LMK_PASSES; ++b) {
         if (b * 7 >= nl) break;                             // wave-uniform
         const int li = b * 7 + g;
-        const int rows = __shfl(q.rows, li, 64);
+        const int rows = __shfl(my_rows, li, 64);
         if (g < 7 && li < nl) {
             // a landmark that spans tiles: the sum of THIS tile's part alone (the prior joins in k_lmk_finish_parts)
             double acc = (rows & (ROWS_CONT | ROWS_MORE)) ? 0.0 : q.pri[b];
@@ -466,8 +494,8 @@ GBP_DEV void tile_landmark_beliefs(const Params &p, double *wl, int lane, int t,
         double b[9];
 #pragma unroll
         for (int k2 = 0; k2 < 9; ++k2) b[k2] = wl[lane * 9 + k2];
-        if (q.rows & (ROWS_CONT | ROWS_MORE)) {             // (at most the first and the last landmark of a tile)
-            double *dst = p.parts + ((size_t)2 * t + ((q.rows & ROWS_CONT) ? 0 : 1)) * PART_ROW;
+        if (my_rows & (ROWS_CONT | ROWS_MORE)) {            // (at most the first and the last landmark of a tile)
+            double *dst = p.parts + ((size_t)2 * t + ((my_rows & ROWS_CONT) ? 0 : 1)) * PART_ROW;
 #pragma unroll
             for (int k2 = 0; k2 < 9; ++k2) dst[k2] = b[k2];
         } else {
