@@ -333,6 +333,26 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
 
         double MCn[21], eC[6];
         int tile_relin = 0;                                // factors of this tile that relinearised (valid in its active lanes)
+        // PINNED only.  The compiler guards the first reuse of the gather's registers, at the top of the NEXT iteration, with a wait for
+        // everything older than that iteration's own loads: on the path around the `if (active)` block below (no lane active: never the
+        // case, a tile has a factor, but it cannot know) the gather counts as still in flight at the loop's back edge.  In the plain
+        // kernel that guard is s_waitcnt vmcnt(11) with thirteen loads outstanding, and removing it bought nothing (EXPERIMENTS.md round 6).
+        // Here the stream loads sit in two branches each (nontemporal or not, per tile), the guard cannot count them and becomes
+        // s_waitcnt vmcnt(0): every wave waited for ALL its streams in front of the belief phase that is there to run while they fly.
+        // So: the geometry first (it needs no belief: the gather's round trip), then EVERY lane waits for the gather, outside the block.
+        Lin geom;
+        if (PINNED) {
+            if (active) {
+                Params q = p;
+                pin_scalars(q);
+                factor_geometry(q, x0, z, geom);
+            }
+            // (all 27 values: which of the gather's loads goes out last is the compiler's choice)
+            asm volatile("" ::"v"(muC[0]), "v"(muC[1]), "v"(muC[2]), "v"(muC[3]), "v"(muC[4]), "v"(muC[5]), "v"(PC[0]), "v"(PC[1]), "v"(PC[2]), "v"(PC[3]),
+                         "v"(PC[4]), "v"(PC[5]), "v"(PC[6]), "v"(PC[7]));
+            asm volatile("" ::"v"(PC[8]), "v"(PC[9]), "v"(PC[10]), "v"(PC[11]), "v"(PC[12]), "v"(PC[13]), "v"(PC[14]), "v"(PC[15]), "v"(PC[16]), "v"(PC[17]),
+                         "v"(PC[18]), "v"(PC[19]), "v"(PC[20]));
+        }
         if (active) {
             double MLn[6], eL[3], muL[3];
             const double *lhead = wl + (meta & ((1u << META_LMK_BITS) - 1u)) * LHEAD;     // intact until the messages go in below
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
                                                             st2(lin_w, 2048u + lo, x[4], x[5]); st2(lin_w, 3072u + lo, x[6], x[7]);
                                                             st1(lin_w, 4096u + lo, x[8]);
                                                         },
-                                                        qC, qL, WC, VL, eC, eL, MCn, MLn);
+                                                        qC, qL, WC, VL, eC, eL, MCn, MLn, nullptr, PINNED ? &geom : nullptr);
             tile_relin = relin_in_wave(relin);
             n_relin += tile_relin;
             GBP_PH_NOWAIT(6);                              // the maths

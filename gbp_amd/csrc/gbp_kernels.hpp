@@ -231,24 +231,23 @@ template <int LOSS, bool XTRA, typename LmkCov, typename StoreX0>
 GBP_HD bool factor_core(const Params &p, double (&x0)[9], const double (&z)[2], int &st, double &avar,
                         double (&muC)[6], double (&PC)[21], double (&muL)[3], LmkCov &&load_PL, StoreX0 &&store_x0,
                         double (&qC)[2], double (&qL)[2], double (&WC)[3], double (&VL)[3],
-                        double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr)
+                        double (&eCn)[6], double (&eLn)[3], double (&MCn)[21], double (&MLn)[6], double *xt = nullptr, const Lin *geom = nullptr)
 {
     // The factor's geometry at its stored linearisation point -- rotation, projection, the 2x9 Jacobian, rho: a quarter of the
     // arithmetic -- needs nothing of the beliefs: it comes FIRST, so that it runs while the camera record, the last thing the sweep
     // gathers, is still on its way (the relinearisation test below is the first instruction to read it; round 5 ran that test first
-    // and every wave sat out the gather's whole round trip).
+    // and every wave sat out the gather's whole round trip).  `geom`: the caller has made it already (fused sweep, PINNED variant).
     Lin L;
-#ifndef GBP_GEOM_LATE                                        // (-DGBP_GEOM_LATE: round 5's order, for A/B runs)
-    factor_geometry(p, x0, z, L);
+    if (geom) {
+        L = *geom;
+    } else {
+        factor_geometry(p, x0, z, L);
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(L.rho[0]), "+v"(L.rho[1]));      // (the order is the point: keep the scheduler from sinking it behind the wait)
+        asm volatile("" : "+v"(L.rho[0]), "+v"(L.rho[1]));      // (the order is the point: keep the scheduler from sinking it behind the wait)
 #endif
-#endif
+    }
     double d;
     const bool relin = factor_decide<LOSS>(p, x0, z, st, avar, muC, muL, d);
-#ifdef GBP_GEOM_LATE
-    factor_geometry(p, x0, z, L);
-#endif
     L.d = d;
     L.s = rcp(avar);
     double PL[6];
