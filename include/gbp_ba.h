@@ -167,9 +167,11 @@ int gbp_ba_comm_init_rccl(gbp_ba_t *h, const void *id128, int32_t rank, int32_t 
 int gbp_ba_set_exchange(gbp_ba_t *h, gbp_exchange_fn fn, void *ctx, int32_t rank, int32_t n_ranks, int32_t flags);
 int gbp_ba_comm_destroy(gbp_ba_t *h);
 /*   - gbp_ba_peer_export / gbp_ba_peer_connect: NO collective call.  Every rank owns a mailbox in its own device memory (two
- *     sweep-parity halves of n_ranks x C rows: a camera's 27 partial sums + a tag); the kernel that finishes a rank's partial sums
- *     stores each row straight into the mailbox of every rank (peer stores over xGMI on a multi-GPU node) and then raises the
- *     row's tag; whoever finishes camera c polls the n_ranks tags of row c in its own mailbox.  After the fused sweep all of that
+ *     sweep-parity halves of n_ranks x C rows: a camera's 27 partial sums + pad); the kernel that finishes a rank's partial sums
+ *     stores each row straight into the mailbox of every rank (peer stores over xGMI on a multi-GPU node).  The data is its own
+ *     arrival flag: an empty slot holds a quiet NaN with a payload no arithmetic produces, whoever finishes camera c polls the
+ *     n_ranks rows c of its own mailbox until no slot is empty (the poll is the data load) and empties them again for the exchange
+ *     after next: one trip per exchange, no acknowledgement wait, no tag, no ordering asked of the link.  After the fused sweep all of that
  *     is ONE launch (reduce -> push -> wait -> rank-ordered sum + prior + 6x6 solve).  export allocates the mailbox for n_ranks and
  *     writes a 64-byte handle (a hipIpcMemHandle_t for other PROCESSES; with GBP_PEER_SAME_PROCESS the raw device address, for
  *     ranks that are threads of one process); carry the handles of all ranks, in rank order, to every rank over any side channel
@@ -185,7 +187,7 @@ int gbp_ba_comm_destroy(gbp_ba_t *h);
 #define GBP_PEER_MAX_RANKS 16
 int gbp_ba_peer_export(gbp_ba_t *h, int32_t n_ranks, void *handle64, int32_t flags);
 int gbp_ba_peer_connect(gbp_ba_t *h, int32_t rank, int32_t n_ranks, const void *handles, int32_t flags);
-/* after connect (and a side-channel barrier), before the first sharded call, on every rank: one tagged probe row travels to every
+/* after connect (and a side-channel barrier), before the first sharded call, on every rank: one probe row travels to every
  * rank's mailbox exactly as a sweep's rows do and the rows of all ranks are checked on arrival.  GBP_ESTATE names the pair that failed
  * (row late, or wrong contents); the caller then uses the RCCL exchange (gbp_amd/sharded.py does, and records why). */
 int gbp_ba_peer_selftest(gbp_ba_t *h, int32_t timeout_ms);

@@ -1,6 +1,6 @@
 """One rank of tests/test_peer_ipc_gpu.py: a separate PROCESS that shares GPU 0 with the other ranks.  The process group is gloo
 (ranks on one GPU cannot form an RCCL group); the camera partial sums travel through the peer-store exchange: hipIpc-mapped
-mailboxes, direct stores, tag waits inside the kernels."""
+mailboxes, direct stores, arrival polls inside the kernels."""
 import os
 import sys
 
