@@ -458,6 +458,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     }
     GBP_PH(11);                                            // table write-out
     GBP_PH_FLUSH(a.phase, blockIdx.x * NWAVES + wave);
+#ifdef GBP_END_STAMP                                        // (tools/boundary_probe.py: when did the LAST workgroup get here?)
+    if (a.clk && tid == 0) atomicMax(a.clk + 1, (unsigned long long)wall_clock64());
+#endif
 }
 
 // One workgroup per camera: partial[c] = sum over the per-workgroup tables in a fixed order (bitwise reproducible).
@@ -536,6 +539,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_cam_reduce_tree(Params p, const
         for (int k = 0; k < 27; ++k) v[k] = tot[k];
         cam_belief_store(v, rec, tid);
     }
+#ifdef GBP_END_STAMP
+    if (clk && tid == 0) atomicMax(clk + 1, (unsigned long long)wall_clock64());
+#endif
 }
 
 // Camera windows leave a camera a handful of rows (those of the workgroups whose camera set holds it: two to five in a sequence, where
