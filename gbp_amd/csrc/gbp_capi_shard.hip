@@ -229,7 +229,7 @@ int gbp_ba_peer_selftest(gbp_ba_t *h, int32_t timeout_ms)
     if (!pe.connected) return fail(GBP_ESTATE, "peer exchange: self-test before gbp_ba_peer_connect");
     const int n = pe.n_ranks;
     PeerOut po{};
-    po.n = n; po.seq = 0x9b50000000000000ull | ++pe.probe_seq;
+    po.n = n; po.C = h->p.C; po.stale = nullptr; po.seq = 0x9b50000000000000ull | ++pe.probe_seq;
     for (int r = 0; r < n; ++r) po.dst[r] = peer_probe(h, pe.base[r], n, pe.rank);
     int clk_khz = 0;
     if (hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || clk_khz <= 0) clk_khz = 100000;
@@ -254,7 +254,8 @@ static int sharded_step_peer(gbp_ba *h, int with_messages, int robustify, int lo
     gbp_ba::Peer &pe = h->peer;
     const int n = pe.n_ranks, half = (int)(++pe.seq & 1ull);
     PeerOut po{};
-    po.n = n; po.seq = pe.seq;
+    po.n = n; po.C = h->p.C; po.seq = pe.seq;
+    po.stale = peer_data(h, pe.mailbox, n, half ^ 1, 0);      // what the previous exchange delivered here: read then, emptied by this push
     for (int r = 0; r < n; ++r) po.dst[r] = peer_data(h, pe.base[r], n, half, pe.rank);
     PeerWait w{peer_data(h, pe.mailbox, n, half, 0), pe.seq, pe.timeout_ticks, pe.d_ctl + 1, nullptr};
     // Without a rendezvous hook everything behind the fused sweep is ONE launch (k_cam_reduce_xchg); logical ranks on one device

@@ -630,6 +630,10 @@ __global__ __launch_bounds__(XCHG_THREADS) void k_cam_reduce_xchg(Params p, cons
         }
     }
     for (int c = blockIdx.x + wave * gridDim.x; c < p.C; c += (XCHG_THREADS / 64) * gridDim.x) cam_finish_wave(p, nullptr, peer.n, 0, wait, c, lane);
+#ifdef GBP_END_STAMP
+    __syncthreads();
+    if (clk && tid == 0) atomicMax(clk + 1, (unsigned long long)wall_clock64());
+#endif
 }
 
 

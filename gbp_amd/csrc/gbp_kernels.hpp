@@ -562,9 +562,9 @@ GBP_DEV void landmark_belief_from_hbm(const Params &p, int l)
 //
 // ONE trip per exchange (round 6).  THE DATA IS ITS OWN ARRIVAL FLAG: an empty mailbox slot holds PEER_EMPTY -- a quiet NaN with a
 // payload no arithmetic produces -- the sender just stores its 27 doubles (each an 8-byte single-copy-atomic store, fire and forget),
-// the finisher's poll IS its data load (repeat until no slot of the row is empty), and it puts PEER_EMPTY back into the slots it has
-// read -- by the two-halves argument above that reset is long complete (a kernel boundary and a whole exchange lie in between) before
-// any peer stores into the slot again.  Rounds 3-5 stored the row, waited for the stores' acknowledgements (s_waitcnt vmcnt(0): data
+// the finisher's poll IS its data load (repeat until no slot of the row is empty), and the slots it has read are emptied again ONE
+// EXCHANGE LATER, at the start of the next push (peer_push_row) -- by the two-halves argument above long before any peer stores into them
+// again (that peer must first finish the exchange this push belongs to, and run a sweep).  Rounds 3-5 stored the row, waited for the stores' acknowledgements (s_waitcnt vmcnt(0): data
 // before tag), raised a tag, and the finisher polled the tag and THEN loaded the row: four dependent memory round trips per exchange --
 // across xGMI each is microseconds -- where this has two (the stores' flight, the poll that finds them), and no ordering between
 // different addresses is asked of the link at all.
@@ -579,8 +579,10 @@ constexpr unsigned long long PEER_EMPTY = ((unsigned long long)PEER_EMPTY32 << 3
 constexpr int PEER_CHUNK = 8;                         // rows of a camera polled together (one trip for up to eight ranks)
 struct PeerOut {
     int n;                                            // ranks (0: no peer stores)
+    int C;                                            // cameras (rows per rank block)
     double *dst[MAX_PEERS];                           // rank r's mailbox half of this sweep, the block of THIS rank: [C][PEER_ROW]
     unsigned long long seq;                           // exchange number (1, 2, ...): the self-test's probe values depend on it
+    double *stale;                                    // THIS rank's mailbox half of the PREVIOUS exchange: [n][C][PEER_ROW], read then, emptied now
 };
 struct PeerWait {
     double *src;                                      // this rank's mailbox half: [n_parts][C][PEER_ROW], or NULL (parts are plain arrays)
@@ -596,14 +598,22 @@ GBP_DEV bool peer_is_empty(double v) { return (unsigned long long)__double_as_lo
 GBP_DEV double peer_empty_value() { return __longlong_as_double((long long)PEER_EMPTY); }
 
 // ONE wave: lanes 0..26 hold camera c's partial sums; row c of this rank's block in every mailbox gets them.  Nothing to wait for.
+// The same wave first empties the rows c of the OTHER half of its own mailbox -- what the previous exchange delivered and this rank's
+// finish has read, one kernel ago -- for the exchange after this one.  (Emptied by the finisher right after its read, the write-through
+// resets were the last stores of the launch and the kernel boundary behind it waited for their round trip: 5.7 us from the last
+// workgroup to the next sweep's start where the plain reduce has 3.2, tools/boundary_probe.py.  Here they have the whole launch to land.)
+// A peer stores into those slots again only after its finish of THIS exchange, which needs the push below, and a sweep of its own.
 GBP_DEV void peer_push_row(const PeerOut &peer, int c, double v, int lane)
 {
+    if (peer.stale)
+        for (int r = 0; r < peer.n; ++r)
+            if (lane < 27) peer_store(peer.stale + ((size_t)r * peer.C + c) * PEER_ROW + lane, peer_empty_value());
     for (int r = 0; r < peer.n; ++r)
         if (lane < 27) peer_store(peer.dst[r] + (size_t)c * PEER_ROW + lane, v);
 }
 
 // ONE wave: entry `lane` (< 27) of rows c of parts r0 .. r0 + PEER_CHUNK - 1 (those below n_parts) of the mailbox half `src`
-// ([n_parts][C][PEER_ROW]), polled until none of them is empty, then emptied again for the exchange after next.  false on time-out.
+// ([n_parts][C][PEER_ROW]), polled until none of them is empty (they are emptied again one exchange later: peer_push_row).  false on time-out.
 GBP_DEV bool peer_take_rows(const PeerWait &wait, int n_parts, int C, int c, int r0, int lane, double (&v)[PEER_CHUNK], long long t0)
 {
     bool ok = true;
@@ -626,9 +636,6 @@ GBP_DEV bool peer_take_rows(const PeerWait &wait, int n_parts, int C, int c, int
         if (lane == 0) atomicExch(wait.err, 1);
         return false;
     }
-#pragma unroll
-    for (int j = 0; j < PEER_CHUNK; ++j)
-        if (lane < 27 && r0 + j < n_parts) peer_store(wait.src + ((size_t)(r0 + j) * C + c) * PEER_ROW + lane, peer_empty_value());
     return true;
 }
 

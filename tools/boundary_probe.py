@@ -21,10 +21,14 @@ out = {}
 for n_l in [int(a) for a in sys.argv[1:]] or [100_000, 12_500, 200_000]:
     p = make_synthetic(n_cams=500, n_lmks=n_l, obs_per_lmk=10, seed=0)
     e = BAEngine.from_problem(p)
-    e.generate_priors_var(50.0); e.update_all_beliefs(); e.sync(); e.snapshot_state()
+    it, upd = e.iterate, e.update_all_beliefs
+    if os.environ.get('PEER'):                               # the sharded loop with the one-rank peer exchange (tools/shard_probe.py `peer1`)
+        e.peer_connect(0, [e.peer_export(1)])
+        it, upd = e.iterate_sharded, e.update_beliefs_sharded
+    e.generate_priors_var(50.0); upd(); e.sync(); e.snapshot_state()
     e.set_kernel_timing(1 << 30)
     for _ in range(20):
-        e.restore_snapshot(); e.iterate(7)
+        e.restore_snapshot(); it(7)
     e.sync()
     c = e.sweep_clocks()
     c = c[-70:]
@@ -38,4 +42,4 @@ for n_l in [int(a) for a in sys.argv[1:]] or [100_000, 12_500, 200_000]:
     print(p.n_factors, {k: round(v, 2) for k, v in res.items()}, flush=True)
     e.close()
 os.makedirs('gpurun_out', exist_ok=True)
-json.dump(out, open('gpurun_out/boundary_probe.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/boundary_probe%s.json' % ('_peer' if os.environ.get('PEER') else ''), 'w'), indent=1)
