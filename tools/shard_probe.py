@@ -24,8 +24,10 @@ for n_l in args.sizes:
         os.environ.pop('GBP_WINDOWS', None)
         if mode.endswith('_whole'):
             os.environ['GBP_WINDOWS'] = '0'
+        if mode.endswith('_win'):                            # camera sets whenever they fit (GBP_WINDOWS=1), whatever the plan's threshold says
+            os.environ['GBP_WINDOWS'] = '1'
         e = BAEngine.from_problem(p, fused=(mode not in ('general', 'peer1g')))
-        if mode in ('peer1', 'peer1g', 'peer1_whole'):              # peer1g: the general sweep under the exchange (k_sweep_staged + k_cam_staged_xchg)
+        if mode in ('peer1', 'peer1g', 'peer1_whole', 'peer1_win'):              # peer1g: the general sweep under the exchange (k_sweep_staged + k_cam_staged_xchg)
             e.peer_connect(0, [e.peer_export(1)])
             it, upd = e.iterate_sharded, e.update_beliefs_sharded
         else:
