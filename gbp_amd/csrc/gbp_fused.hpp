@@ -210,7 +210,22 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
     __syncthreads();
     // the workgroup's contiguous range of tiles, computed (a table of range starts cost a dependent load before the first tile)
-    const int tb = (int)((long long)blockIdx.x * p.T / gridDim.x), ntl = (int)((long long)(blockIdx.x + 1) * p.T / gridDim.x) - tb;
+    // STRIDED WALK beyond the memory-side cache (round 6).  With a contiguous range per workgroup the sweep reads 256 streams that lie
+    // megabytes apart, and how evenly those fall on the HBM channels depends on where the driver happened to put the pages: the same
+    // binary ran 6 % faster or slower from process to process -- from engine to engine inside one process -- ("two modes",
+    // EXPERIMENTS.md rounds 5-6; a plain copy of the same memory does not see it).  Workgroup b walking tiles b, b + n, b + 2 n, ...
+    // keeps all 256 streams inside one moving window of a few megabytes: every one of sixteen engines behind different amounts of other
+    // memory lands at or below the old fast mode (2M factors 158.5-161.0 us per step against 165.0-171.1, 10M 698 against 722).  The tiles
+    // a workgroup keeps cacheable (FusedArgs::pin) are then one contiguous piece of the graph.  Not with camera windows: a workgroup's
+    // camera set lives on its tiles being neighbours.  Not below the cache size: there the contiguous walk is as fast (round 5: 74.6
+    // against 74.3 us) and the plain kernel stays as it is.  (-DGBP_CONTIGUOUS_PINNED: the old walk, for A/B runs.)
+#if defined(GBP_CONTIGUOUS_PINNED)
+    constexpr bool STRIDED = false;
+#else
+    constexpr bool STRIDED = PINNED && !WINDOWED && !STAGED;
+#endif
+    const int tb = STRIDED ? 0 : (int)((long long)blockIdx.x * p.T / gridDim.x);
+    const int ntl = STRIDED ? (p.T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : (int)((long long)(blockIdx.x + 1) * p.T / gridDim.x) - tb;
 
     // The landmark beliefs of a tile (LDS work, no loads) are formed one iteration LATE, after the next tile's loads have
     // been issued, so that the wave has HBM requests in flight meanwhile.  The tile's landmark messages wait in the wave's LDS
@@ -239,7 +254,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         if (lane == 0) ti = atomicAdd(&ctl[0], 1);
         ti = __builtin_amdgcn_readfirstlane(ti);
         const bool valid = ti < ntl;
-        const int t = tb + (valid ? (a.reverse ? ntl - 1 - ti : ti) : 0);
+        const int li = valid ? (a.reverse ? ntl - 1 - ti : ti) : 0;      // position in the workgroup's walk
+        const int t = STRIDED ? li * (int)gridDim.x + (int)blockIdx.x : tb + li;
         GBP_PH(0);                                         // ticket
         if (!valid) {                                      // no tile left: the landmark beliefs of this wave's last tile, and out
             if (pend && !GBP_DBG(a, 4)) tile_landmark_beliefs(p, wl, lane, q_t, q_l0, q_nl, pre);
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
         //  copies that would make the wave wait for them before the tail below)
         // this tile streams past the memory-side cache: FusedArgs::pin; every tile of the general sweep (the cache is left to the staged
         // camera rows: nontemporal message stores as well as loads, 116.6-117.3 against 119.4-119.7 us per sweep with plain stores)
-        const bool past = STAGED || (PINNED && (t - tb) >= a.pin);
+        const bool past = STAGED || (PINNED && li >= a.pin);
         issue_streams<LOSS, STAGED>(p, t, lane, S, past ? 3 : (PINNED ? a.nt : 0));      // (FusedArgs::nt: experiments with the pinned variant only)
 #if GBP_PF_DIST > 0
         Touch pf;
@@ -823,7 +839,11 @@ inline int fused_plan(FusedPlan &pl, const Params &p, hipStream_t stream, int n_
         const double per_tile = WTILE * (LIN_ROWS + MSG_ROWS) * 8.0 + (double)p.L * LREC * 8 / std::max(p.T, 1);
         // (the share that pays shrinks with the distance from the cache size: 200 MiB just beyond it -- 67.1 against 70.7 ps per factor at
         //  1.15M factors with 160 -- 140 from 1.5M factors on: 73.4 against 76.2 / 78.3 with 180 / 220)
-        double keep_mib = touched > 256.0 * MiB ? std::min(200.0, std::max(140.0, 460.0 - touched / MiB)) : -1.0;      // < 0: everything stays cacheable
+        // (round 6, with the strided walk of the pinned variant -- the cacheable tiles are one contiguous piece of the graph then -- a larger
+        //  share pays than the 140-200 MiB above: 1.15M factors 73.6 us per launch with 240 MiB against 76.9 with 200; 1.35M 88.1 with 220,
+        //  89.0 with 240, 90.9 with 200, 93.0 with 140; 2M 134.4 with 200, 137.0 with 220, 139.0 with 140, 141.3 with 240; 3M 205.4 with
+        //  200, 210.5 with 220; 10M flat: profiles/r06_keep_sweep.txt)
+        double keep_mib = touched > 256.0 * MiB ? (touched < 350.0 * MiB ? 230.0 : 200.0) : -1.0;      // < 0: everything stays cacheable
         if (const char *e = getenv("GBP_FUSED_PIN_MIB")) keep_mib = atof(e);
         pl.args.nt = 0;
         pl.args.pin = 0x7fffffff;
