@@ -639,7 +639,8 @@ def main(shard_factory=None, script=None):
             def frac_of(ms, peak=HBM_PEAK_GBS):
                 return lay / (ms * 1e-3) / 1e9 / peak
             k_med, k_min, k_max = float(np.median(ks_all)), min(ks_all), max(ks_all)
-            # the two modes of this quantity sit ~6 % apart (0.455-0.48 | 0.50-0.51 at 2M factors): which one did this process land in?
+            # Rounds 4-5: two modes ~6 % apart (0.455-0.48 | 0.50-0.51 at 2M factors) by where the driver had put the pages.  Since round 6 the
+            # sweep of these sizes walks its tiles strided and every placement measured lands at 0.53-0.55: "slow" would be a regression.
             mode = "fast" if frac_of(k_med) >= 0.49 else "slow"
             out = {"n_factors": int(big.n_factors), "n_lmks": int(big.n_lmks), "sweep": "fused" if fused_big else "general",
                    "kernel_avg_ms": k_med, "kernel_avg_ms_range": [k_min, k_max], "replays": REPLAYS, "bytes_per_launch": lay,
@@ -647,7 +648,8 @@ def main(shard_factory=None, script=None):
                    "frac_of_copy_ceiling": frac_of(k_med, COPY_CEILING_GBS), "mode": mode,
                    "note": "same kernel, sweeps 6-25 of the batch schedule (two of them relinearise every factor and move 72 B per factor more than "
                            f"bytes_per_launch counts), MEDIAN of {REPLAYS} replays with min / max beside it; state >> the 256 MiB memory-side cache; "
-                           "`mode`: the same binary lands in one of two modes ~6 % apart from process to process (EXPERIMENTS.md round 5)"}
+                           "`mode`: rounds 4-5 landed in one of two modes ~6 % apart by memory placement (0.455-0.48 | 0.50-0.51); the strided tile walk of round 6 "
+                           "removed that (0.53-0.55 in every placement measured): 'slow' (< 0.49) would be a regression"}
             if ks_steady:
                 s_med = float(np.median(ks_steady))
                 out.update({"kernel_steady_ms": s_med, "kernel_steady_ms_range": [min(ks_steady), max(ks_steady)], "kernel_steady_launches": n_steady,

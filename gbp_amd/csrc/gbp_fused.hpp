@@ -218,11 +218,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_sweep_wat(Params p, FusedArgs a
     // memory lands at or below the old fast mode (2M factors 158.5-161.0 us per step against 165.0-171.1, 10M 698 against 722).  The tiles
     // a workgroup keeps cacheable (FusedArgs::pin) are then one contiguous piece of the graph.  Not with camera windows: a workgroup's
     // camera set lives on its tiles being neighbours.  Not below the cache size: there the contiguous walk is as fast (round 5: 74.6
-    // against 74.3 us) and the plain kernel stays as it is.  (-DGBP_CONTIGUOUS_PINNED: the old walk, for A/B runs.)
+    // against 74.3 us) and the plain kernel stays as it is.  (-DGBP_CONTIGUOUS_PINNED: the old walk everywhere, for A/B runs.)
 #if defined(GBP_CONTIGUOUS_PINNED)
     constexpr bool STRIDED = false;
 #else
-    constexpr bool STRIDED = PINNED && !WINDOWED && !STAGED;
+    // (the general sweep -- STAGED: every stream nontemporal, the working set far beyond the cache at any size that matters -- the same:
+    //  117.7-119.8 -> 113.6-113.9 us per sweep at 1M factors x 500 cameras, 123.9-125.1 -> 118.4-118.9 at 2 000; its camera sums are made in
+    //  the cameras' own order by another kernel, so its results do not change by a bit)
+    constexpr bool STRIDED = (PINNED && !WINDOWED) || STAGED;
 #endif
     const int tb = STRIDED ? 0 : (int)((long long)blockIdx.x * p.T / gridDim.x);
     const int ntl = STRIDED ? (p.T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : (int)((long long)(blockIdx.x + 1) * p.T / gridDim.x) - tb;
