@@ -62,21 +62,20 @@ def test_sharded_random_shapes(oracle_mod, seed):
     # How far are two correct implementations apart on this run?  Aggressive settings can make a tiny graph ill-conditioned or blow it up
     # (test_fuzz_gpu.healthy) -- from there on there is nothing to hold the sharded sums against.  Such a run is CUT SHORT at its last sane
     # sweep, not skipped (seed 0 blew up on the single engine too and skipped on every run -- a seed that always skips tests
-    # nothing): first pass = single engine and oracle sweep by sweep, the schedule ends in front of the first sweep after which the
-    # oracle's state is unhealthy or the two are more than 1e-4 apart; the comparison below runs on that schedule.
-    from test_fuzz_gpu import healthy
+    # nothing): first pass = single engine and oracle sweep by sweep, the schedule ends in front of the first sweep after which the two are
+    # more than 1e-4 apart (or not finite); the comparison below runs on that schedule.
     probe = BAEngine.from_problem(p, fused=fused, **cfg)
     o = oracle_mod.OracleBA.from_problem(p, threads=4, **cfg)
     for g in (probe, o):
         g.generate_priors_var(30.0)
         g.update_all_beliefs()
-    are0, cut = o.are(), 0
+    cut = 0
     for rob, rel in flags:
         for g in (probe, o):
             g.synchronous_iteration(robustify=rob, local_relin=rel)
         pb = probe.beliefs()
         gap = max(rel_err_rows(a, b) for a, b in zip(pb, o.beliefs()))
-        if not (np.isfinite(gap) and gap <= 1e-4 and all(np.isfinite(x).all() for x in pb) and healthy(o, p, are0)):
+        if not (np.isfinite(gap) and gap <= 1e-4 and all(np.isfinite(x).all() for x in pb)):
             break
         cut += 1
     probe.close()
